@@ -1,0 +1,151 @@
+/*
+ * nvqa.h -- C ABI of libnvqa, the MI355X (gfx950) implementation of the VQA
+ * training step of srama2512/novel-vqa.
+ *
+ * Every entry point below replaces one piece of the reference's Lua/Torch7
+ * interface for the hot path (paths relative to the reference checkout):
+ *
+ *   nvqa_create / nvqa_destroy     net construction + :cuda()
+ *                                  002_train_vqa_arch1/002_train_baseline.lua:141-171
+ *                                  003_train_vqa_arch2/002_train_baseline.lua:138-177
+ *   nvqa_param_count / _segments   sizes={...}; join_vector({...})
+ *                                  002_train_baseline.lua:183,190 (arch2 :189,198)
+ *   nvqa_init_params               *_w:uniform(-0.08,0.08)        002_train_baseline.lua:174-181
+ *   nvqa_set_params/_get_params    split_vector + :copy            002_train_baseline.lua:273-286,
+ *                                  004_eval_model.lua:154-163
+ *   nvqa_step                      the optim closure JdJ(x)        002_train_baseline.lua:272-335
+ *                                  (arch2 :277-333); batch = dataset:next_batch() :195-222
+ *   nvqa_get_grads                 `gradients` returned by JdJ incl. clamp :328-329
+ *   nvqa_rmsprop_update            optim.rmsprop(JdJ, x, config, state) :408,
+ *                                  formula misc/rmsprop_lrscale.lua:13-34
+ *   nvqa_forward                   eval-mode forward + argmax      004_eval_model.lua:202-233
+ *   nvqa_dataset_load /            dataset[...] tensors + dataset:next_batch() gather
+ *   nvqa_step_indices              002_train_baseline.lua:93-121,195-222
+ *   nvqa_comm_*                    (absent in the reference: data-parallel gradient all-reduce)
+ *
+ * Conventions: plain C, POD arguments only.  All pointers are caller-owned
+ * host memory borrowed for the duration of the call; device buffers, streams,
+ * optimiser state and the RCCL communicator are owned by the context.  No
+ * entry point throws or longjmps: 0 = success, negative = error, message via
+ * nvqa_last_error() (thread-local).  Indices follow the reference's data
+ * files: tokens 1..V (0 = padding), labels 1..A, image positions 1..N_img.
+ */
+#ifndef NVQA_H
+#define NVQA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVQA_ARCH1 1 /* 002_train_vqa_arch1: Linear(V,E) embedding, n-layer LSTM, AxB fusion */
+#define NVQA_ARCH2 2 /* 003_train_vqa_arch2: image-as-first-token nn.Encoder, Linear(R,A) head */
+
+/* Model dimensions (SURVEY.md symbol table). */
+typedef struct nvqa_dims {
+    int32_t arch; /* NVQA_ARCH1 | NVQA_ARCH2 */
+    int32_t B;    /* minibatch (QA pairs) per device             -batch_size          */
+    int32_t T;    /* question buffer length (columns of ques_*)  buffer_size_q        */
+    int32_t V;    /* question vocabulary size                    vocabulary_size_q    */
+    int32_t E;    /* word embedding width                        -input_encoding_size */
+    int32_t R;    /* LSTM hidden size                            -rnn_size            */
+    int32_t L;    /* LSTM layers                                 -rnn_layer/-num_layers */
+    int32_t I;    /* image feature width                         -nhimage             */
+    int32_t C;    /* common embedding width (arch1 only)         -common_embedding_size */
+    int32_t A;    /* answer classes                              -num_output          */
+} nvqa_dims;
+
+/* Dropout control.  Torch7's MT19937 bernoulli stream cannot be reproduced, so
+ * masks come from the counter-based generator of nvqa_rng.h, identical on the
+ * CPU oracle and on the device.  mode 0 = every D_* = 1 (gradient/logit parity
+ * runs); mode 1 = Bernoulli(1-p) masks scaled by 1/(1-p), keyed by
+ * (seed, step, site, element). */
+typedef struct nvqa_dropout {
+    int32_t mode;  /* 0 off, 1 seeded */
+    float p;       /* drop probability, reference value 0.5 */
+    uint64_t seed; /* reference default -seed 123 */
+    uint64_t step; /* iteration counter, mixed into every mask */
+} nvqa_dropout;
+
+typedef struct nvqa_ctx nvqa_ctx;
+
+/* ---- lifetime ------------------------------------------------------- */
+int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out);
+int nvqa_destroy(nvqa_ctx *ctx);
+const char *nvqa_last_error(void);
+int nvqa_sync(nvqa_ctx *ctx); /* wait for all enqueued work (loss_out becomes valid) */
+
+/* ---- parameters: one flat fp32 vector, reference segment order ------- */
+/* arch1: [encoder | embedding | multimodal]; arch2: [cnn | encoder | multimodal].
+ * Intra-segment order (documented in DESIGN.md):
+ *  arch1 encoder   : per layer W_i2h[4R x in], b_i2h[4R], W_h2h[4R x R], b_h2h[4R]
+ *  arch1 embedding : W_e[E x V] (Torch nn.Linear layout), b_e[E]
+ *  arch1 multimodal: W_q[C x 2RL], b_q[C], W_v[C x I], b_v[C], W_o[A x C], b_o[A]
+ *  arch2 cnn       : W_p[E x I], b_p[E]
+ *  arch2 encoder   : LSTM layers as above, then lookup W_lk[(V+1) x E]
+ *  arch2 multimodal: W_o[A x R], b_o[A]                                         */
+size_t nvqa_param_count(const nvqa_ctx *ctx);
+int nvqa_segments(const nvqa_ctx *ctx, size_t sizes_out[3]);
+int nvqa_init_params(nvqa_ctx *ctx, uint64_t seed, float lo, float hi);
+int nvqa_set_params(nvqa_ctx *ctx, const float *params);
+int nvqa_get_params(nvqa_ctx *ctx, float *params_out);
+/* Gradient of the last step, reference layout; clamp > 0 applies
+ * clamp(-clamp, clamp) on the way out (JdJ returns clamped gradients). */
+int nvqa_get_grads(nvqa_ctx *ctx, float *grads_out, float clamp);
+
+/* ---- the hot path ---------------------------------------------------- */
+/* One forward+backward over a host-resident minibatch (the body of JdJ).
+ *  arch1: tokens [B x T] right-aligned, 0 = left padding (right_align,
+ *         misc/RNNUtils.lua:54-61); lengths [B] >= 1.
+ *  arch2: tokens [B x T] left-aligned, 0 = null token (the library forms the
+ *         reference's [T x B] transpose itself); lengths may be NULL.
+ *  img [B x I] (already L2-normalised, 002_train_baseline.lua:117-121);
+ *  labels [B], 1-based.  The mean cross-entropy is written to *loss_out once
+ *  the work has drained (nvqa_sync or the next call). Gradients stay on the
+ *  device for nvqa_rmsprop_update / nvqa_get_grads. */
+int nvqa_step(nvqa_ctx *ctx, const int32_t *tokens, const int32_t *lengths, const float *img,
+              const int32_t *labels, const nvqa_dropout *dropout, float *loss_out);
+
+/* Evaluate-mode forward (all dropout = identity): scores [n x A] and/or
+ * 1-based argmax [n] (either may be NULL), n <= B rows. */
+int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t *lengths,
+                 const float *img, float *scores_out, int32_t *argmax_out);
+
+/* clamp -> (+ wd * x) -> m = alpha m + (1-alpha) g^2 -> x -= lr g / (sqrt(m) + eps).
+ * With a communicator the gradient is first summed over ranks and divided by
+ * the world size; the clamp acts on that average. */
+int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
+
+/* ---- HBM-resident dataset (the tensors of 002_train_baseline.lua:93-121) ---- */
+/* questions [N x T] (aligned as nvqa_step expects), lengths [N], img_pos [N]
+ * (1-based rows of feats), answers [N] (1-based), feats [N_img x I]. */
+int nvqa_dataset_load(nvqa_ctx *ctx, int64_t n_q, const int32_t *questions, const int32_t *lengths,
+                      const int32_t *img_pos, const int32_t *answers, int64_t n_img,
+                      const float *feats, int l2_normalize);
+/* JdJ with dataset:next_batch() done on the device: qinds [B], 0-based rows. */
+int nvqa_step_indices(nvqa_ctx *ctx, const int64_t *qinds, const nvqa_dropout *dropout,
+                      float *loss_out);
+
+/* ---- data parallel (new functionality; the reference is single-GPU) --- */
+#define NVQA_COMM_ID_BYTES 128
+int nvqa_comm_unique_id(void *id_out /* NVQA_COMM_ID_BYTES */);
+int nvqa_comm_init(nvqa_ctx *ctx, int rank, int world, const void *id);
+
+/* ---- measurement ------------------------------------------------------ */
+/* HIP-event timing of kernel groups on the stream they are launched on.
+ * enable=1 brackets every launch with events (slows the step; bench.py uses a
+ * separate timed pass for it). Names: see nvqa_profile_name(). */
+int nvqa_profile_enable(nvqa_ctx *ctx, int enable);
+int nvqa_profile_reset(nvqa_ctx *ctx);
+int nvqa_profile_count(const nvqa_ctx *ctx);
+const char *nvqa_profile_name(const nvqa_ctx *ctx, int idx);
+/* total_ms and launches accumulated since reset; flops = algorithmic FLOPs issued */
+int nvqa_profile_get(nvqa_ctx *ctx, int idx, double *total_ms, int64_t *launches, double *flops,
+                     double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVQA_H */

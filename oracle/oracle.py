@@ -1,0 +1,193 @@
+"""ctypes front-end of the CPU oracle (oracle/nvqa_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product path (novel-vqa_amd/).
+PARITY UNPINNED: see the header of nvqa_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Dims(ctypes.Structure):
+    """Mirror of nvqa_dims (include/nvqa.h)."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Dropout(ctypes.Structure):
+    """Mirror of nvqa_dropout (include/nvqa.h)."""
+
+    _fields_ = [("mode", ctypes.c_int32), ("p", ctypes.c_float), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_uint64)]
+
+
+def make_dims(arch=1, B=4, T=5, V=11, E=6, R=8, L=2, I=12, C=10, A=7):
+    return Dims(arch, B, T, V, E, R, L, I, C, A)
+
+
+def build(force=False):
+    """Compile both oracle libraries with the committed Makefile."""
+    libs = [os.path.join(_HERE, n) for n in ("liboracle_f32.so", "liboracle_f64.so")]
+    src = os.path.join(_HERE, "nvqa_oracle.c")
+    stale = force or any(
+        (not os.path.exists(l)) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
+                              stdout=subprocess.DEVNULL)
+    return libs
+
+
+def layout(dims):
+    """Offsets inside the flat parameter vector; mirrors include/nvqa_layout.h."""
+    d = dims
+    off = 0
+    lo = {}
+
+    def take(name, n):
+        nonlocal off
+        lo[name] = (off, n)
+        off += n
+
+    def lstm():
+        for l in range(d.L):
+            inn = d.E if l == 0 else d.R
+            take(f"w_i2h{l}", 4 * d.R * inn)
+            take(f"b_i2h{l}", 4 * d.R)
+            take(f"w_h2h{l}", 4 * d.R * d.R)
+            take(f"b_h2h{l}", 4 * d.R)
+
+    if d.arch == 1:
+        lstm()
+        s0 = off
+        take("w_e", d.E * d.V)
+        take("b_e", d.E)
+        s1 = off
+        take("w_q", d.C * 2 * d.R * d.L)
+        take("b_q", d.C)
+        take("w_v", d.C * d.I)
+        take("b_v", d.C)
+        take("w_o", d.A * d.C)
+        take("b_o", d.A)
+        lo["_segments"] = (s0, s1 - s0, off - s1)
+    else:
+        take("w_p", d.E * d.I)
+        take("b_p", d.E)
+        s0 = off
+        lstm()
+        take("w_lk", (d.V + 1) * d.E)
+        s1 = off
+        take("w_o", d.A * d.R)
+        take("b_o", d.A)
+        lo["_segments"] = (s0, s1 - s0, off - s1)
+    lo["_total"] = off
+    return lo
+
+
+class Oracle:
+    """One precision (float32 or float64) of the oracle."""
+
+    def __init__(self, dtype=np.float32, threads=None):
+        build()
+        self.dtype = np.dtype(dtype)
+        name = "liboracle_f32.so" if self.dtype == np.float32 else "liboracle_f64.so"
+        self.lib = ctypes.CDLL(os.path.join(_HERE, name))
+        assert self.lib.oracle_real_bytes() == self.dtype.itemsize
+        self.real_p = ctypes.POINTER(ctypes.c_float if self.dtype == np.float32 else ctypes.c_double)
+        self.real_t = ctypes.c_float if self.dtype == np.float32 else ctypes.c_double
+        self.threads = threads
+
+    def _p(self, a):
+        return None if a is None else a.ctypes.data_as(self.real_p)
+
+    @staticmethod
+    def _ip(a):
+        return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+    def step(self, dims, params, tokens, lengths, img, labels, dropout=None, train=True,
+             want_grads=True):
+        """Returns dict(loss, grads (unclamped, flat), scores [B,A], argmax [B] 1-based)."""
+        lo = layout(dims)
+        params = np.ascontiguousarray(params, self.dtype)
+        assert params.size == lo["_total"], (params.size, lo["_total"])
+        tokens = np.ascontiguousarray(tokens, np.int32).reshape(dims.B, dims.T)
+        img = np.ascontiguousarray(img, self.dtype).reshape(dims.B, dims.I)
+        labels_a = None if labels is None else np.ascontiguousarray(labels, np.int32)
+        loss = self.real_t(0)
+        grads = np.zeros(lo["_total"], self.dtype) if (train and want_grads) else None
+        scores = np.zeros((dims.B, dims.A), self.dtype)
+        argmax = np.zeros(dims.B, np.int32)
+        dr = dropout if dropout is not None else Dropout(0, 0.5, 123, 0)
+        if dims.arch == 1:
+            lengths = np.ascontiguousarray(lengths, np.int32)
+            rc = self.lib.oracle_arch1_step(ctypes.byref(dims), self._p(params), self._ip(tokens),
+                                            self._ip(lengths), self._p(img), self._ip(labels_a),
+                                            ctypes.byref(dr), int(train), ctypes.byref(loss),
+                                            self._p(grads), self._p(scores), self._ip(argmax))
+        else:
+            rc = self.lib.oracle_arch2_step(ctypes.byref(dims), self._p(params), self._ip(tokens),
+                                            self._p(img), self._ip(labels_a), ctypes.byref(dr),
+                                            int(train), ctypes.byref(loss), self._p(grads),
+                                            self._p(scores), self._ip(argmax))
+        if rc != 0:
+            raise RuntimeError(f"oracle step failed rc={rc}")
+        return {"loss": float(loss.value), "grads": grads, "scores": scores, "argmax": argmax}
+
+    def rmsprop(self, x, g, m, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
+        """In place on x, g (clamped, + wd x), m."""
+        for a in (x, g, m):
+            assert a.dtype == self.dtype and a.flags.c_contiguous
+        self.lib.oracle_rmsprop(ctypes.c_size_t(x.size), self._p(x), self._p(g), self._p(m),
+                                self.real_t(lr), self.real_t(alpha), self.real_t(eps),
+                                self.real_t(wd), self.real_t(clamp))
+
+    def onehot_linear(self, words, V, We, be):
+        words = np.ascontiguousarray(words, np.int32)
+        We = np.ascontiguousarray(We, self.dtype)
+        be = np.ascontiguousarray(be, self.dtype)
+        E = be.size
+        out = np.zeros((words.size, E), self.dtype)
+        self.lib.oracle_onehot_linear(words.size, V, E, self._ip(words), self._p(We), self._p(be),
+                                      self._p(out))
+        return out
+
+
+# ----------------------------------------------------------------------------
+# Synthetic inputs shared by tests, smoke() and bench.py:
+# tokens uniform in [1,V], image features |N(0,1)| row-L2-normalised,
+# labels uniform in [1,A], params uniform(-0.08, 0.08), seed 123.
+# ----------------------------------------------------------------------------
+def synth_params(dims, seed=123, lo=-0.08, hi=0.08):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(lo, hi, layout(dims)["_total"]).astype(np.float32)
+
+
+def right_align(seq, lengths):
+    """misc/RNNUtils.lua:54-61 : left-aligned rows -> right-aligned, zero left padding."""
+    seq = np.asarray(seq)
+    out = np.zeros_like(seq)
+    n = seq.shape[1]
+    for i, l in enumerate(lengths):
+        out[i, n - l:] = seq[i, :l]
+    return out
+
+
+def synth_batch(dims, seed=123, full_length=True, min_len=1):
+    rng = np.random.default_rng(seed + 1)
+    B, T = dims.B, dims.T
+    lengths = (np.full(B, T) if full_length else rng.integers(min_len, T + 1, B)).astype(np.int32)
+    left = np.zeros((B, T), np.int32)
+    for b in range(B):
+        left[b, :lengths[b]] = rng.integers(1, dims.V + 1, lengths[b])
+    tokens = right_align(left, lengths) if dims.arch == 1 else left
+    img = np.abs(rng.standard_normal((B, dims.I))).astype(np.float32)
+    img /= np.sqrt((img * img).sum(1, keepdims=True))  # 002_train_baseline.lua:117-121
+    labels = rng.integers(1, dims.A + 1, B).astype(np.int32)
+    return tokens, lengths, img, labels

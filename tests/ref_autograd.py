@@ -1,0 +1,142 @@
+"""Independent float64 autograd statement of the arch1 / arch2 equations.
+
+Purpose: cross-check oracle/nvqa_oracle.c (SURVEY.md 8c "how the oracle is
+validated without the reference").  It deliberately uses a DIFFERENT
+formulation from the oracle: no length sort, no time-major packing, the
+literal one-hot x Linear embedding, per-row activity masks, and PyTorch
+autograd instead of hand-written backward passes.
+
+Equations: SURVEY.md Appendix A.1 / A.2 (002_train_vqa_arch1/misc/LSTM.lua:41-59,
+misc/netdef.lua:6-14, 002_train_baseline.lua:141-157,300-320;
+003_train_vqa_arch2/misc/Encoder_lstm.lua:152-263).
+"""
+import numpy as np
+import torch
+
+M64 = (1 << 64) - 1
+
+
+def hash32(seed, step, site, idx):
+    """Python restatement of nvqa_hash32 (include/nvqa_rng.h)."""
+    x = (seed ^ ((0x9E3779B97F4A7C15 * (step + 1)) & M64) ^ ((site << 56) & M64)) & M64
+    x = (x + idx * 0xD1342543DE82EF95) & M64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & M64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & M64
+    x ^= x >> 31
+    return x >> 32
+
+
+def drop_scales(dr, site, shape, index_fn):
+    """Tensor of dropout multipliers; index_fn(*coords) -> element index."""
+    out = np.ones(shape, np.float64)
+    if dr is None or dr.mode == 0:
+        return torch.from_numpy(out)
+    inv_keep = float(np.float32(1.0) / (np.float32(1.0) - np.float32(dr.p)))
+    for coords in np.ndindex(*shape):
+        u = np.float32(hash32(dr.seed, dr.step, site, index_fn(*coords)) >> 8) * np.float32(1.0 / 16777216.0)
+        out[coords] = inv_keep if u >= np.float32(dr.p) else 0.0
+    return torch.from_numpy(out)
+
+
+def _split(params, lo):
+    return {k: params[v[0]:v[0] + v[1]] for k, v in lo.items() if not k.startswith("_")}
+
+
+def _cell(a, c_prev, R):
+    i = torch.sigmoid(a[:, 0:R])
+    f = torch.sigmoid(a[:, R:2 * R])
+    o = torch.sigmoid(a[:, 2 * R:3 * R])
+    g = torch.tanh(a[:, 3 * R:4 * R])
+    c = f * c_prev + i * g
+    return c, o * torch.tanh(c)
+
+
+def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True):
+    d = dims
+    B, T, V, E, R, L, I, C, A = d.B, d.T, d.V, d.E, d.R, d.L, d.I, d.C, d.A
+    params = torch.tensor(np.asarray(params_np, np.float64), requires_grad=True)
+    p = _split(params, lo)
+    drr = dr if train else None
+    We = p["w_e"].view(E, V)
+    tok = np.asarray(tokens).reshape(B, T)
+    c = [torch.zeros(B, R, dtype=torch.float64) for _ in range(L)]
+    h = [torch.zeros(B, R, dtype=torch.float64) for _ in range(L)]
+    De = drop_scales(drr, 0, (B, T, E), lambda b, t, e: (b * T + t) * E + e)
+    Dl = [None] + [drop_scales(drr, 1, (B, T, R), lambda b, t, j, l=l: (((l - 1) * B + b) * T + t) * R + j)
+                   for l in range(1, L)]
+    for t in range(T):
+        active = torch.from_numpy((tok[:, t] != 0).astype(np.float64)).view(B, 1)
+        onehot = torch.zeros(B, V, dtype=torch.float64)
+        for b in range(B):
+            if tok[b, t] != 0:
+                onehot[b, tok[b, t] - 1] = 1.0
+        x = torch.tanh(De[:, t, :] * (onehot @ We.t() + p["b_e"]))
+        for l in range(L):
+            inn = E if l == 0 else R
+            u = x if l == 0 else Dl[l][:, t, :] * h[l - 1]
+            a = u @ p[f"w_i2h{l}"].view(4 * R, inn).t() + p[f"b_i2h{l}"] \
+                + h[l] @ p[f"w_h2h{l}"].view(4 * R, R).t() + p[f"b_h2h{l}"]
+            cn, hn = _cell(a, c[l], R)
+            # rows that have not started keep their zero state (RNNUtils.lua:136-145)
+            c[l] = active * cn
+            h[l] = active * hn
+    q = torch.cat([torch.cat([c[l], h[l]], 1) for l in range(L)], 1)  # [c1 h1 c2 h2] LSTM.lua:70
+    Q = 2 * R * L
+    Dq = drop_scales(drr, 2, (B, Q), lambda b, j: b * Q + j)
+    Dv = drop_scales(drr, 3, (B, I), lambda b, j: b * I + j)
+    Dz = drop_scales(drr, 4, (B, C), lambda b, j: b * C + j)
+    v = torch.tensor(np.asarray(img, np.float64).reshape(B, I))
+    qc = torch.tanh((Dq * q) @ p["w_q"].view(C, Q).t() + p["b_q"])
+    ic = torch.tanh((Dv * v) @ p["w_v"].view(C, I).t() + p["b_v"])
+    scores = (Dz * (qc * ic)) @ p["w_o"].view(A, C).t() + p["b_o"]
+    y = torch.tensor(np.asarray(labels, np.int64) - 1)
+    loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
+    grads = None
+    if train:
+        loss.backward()
+        grads = params.grad.numpy().copy()
+    return {"loss": float(loss.detach()), "scores": scores.detach().numpy(), "grads": grads}
+
+
+def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True):
+    d = dims
+    B, T, V, E, R, L, I, A = d.B, d.T, d.V, d.E, d.R, d.L, d.I, d.A
+    TS = T + 2
+    params = torch.tensor(np.asarray(params_np, np.float64), requires_grad=True)
+    p = _split(params, lo)
+    drr = dr if train else None
+    tok = np.asarray(tokens).reshape(B, T)
+    Wlk = p["w_lk"].view(V + 1, E)
+    v = torch.tensor(np.asarray(img, np.float64).reshape(B, I))
+    c = [torch.zeros(B, R, dtype=torch.float64) for _ in range(L)]
+    h = [torch.zeros(B, R, dtype=torch.float64) for _ in range(L)]
+    Dl = [None] + [drop_scales(drr, 1, (B, TS, R), lambda b, t, j, l=l: (((l - 1) * B + b) * TS + t) * R + j)
+                   for l in range(1, L)]
+    for t in range(1, TS + 1):
+        if t == 1:
+            x = v @ p["w_p"].view(E, I).t() + p["b_p"]
+        elif t == 2:
+            x = Wlk[V].expand(B, E)
+        else:
+            it = tok[:, t - 3].copy()
+            if it.sum() == 0:
+                break
+            it[it == 0] = 1
+            x = Wlk[torch.from_numpy(it.astype(np.int64) - 1)]
+        for l in range(L):
+            inn = E if l == 0 else R
+            u = x if l == 0 else Dl[l][:, t - 1, :] * h[l - 1]
+            a = u @ p[f"w_i2h{l}"].view(4 * R, inn).t() + p[f"b_i2h{l}"] \
+                + h[l] @ p[f"w_h2h{l}"].view(4 * R, R).t() + p[f"b_h2h{l}"]
+            c[l], h[l] = _cell(a, c[l], R)
+    Dh = drop_scales(drr, 2, (B, R), lambda b, j: b * R + j)
+    scores = (Dh * h[L - 1]) @ p["w_o"].view(A, R).t() + p["b_o"]
+    y = torch.tensor(np.asarray(labels, np.int64) - 1)
+    loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
+    grads = None
+    if train:
+        loss.backward()
+        grads = params.grad.numpy().copy()
+    return {"loss": float(loss.detach()), "scores": scores.detach().numpy(), "grads": grads}
