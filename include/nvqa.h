@@ -108,6 +108,10 @@ int nvqa_get_grads(nvqa_ctx *ctx, float *grads_out, float clamp);
 int nvqa_step(nvqa_ctx *ctx, const int32_t *tokens, const int32_t *lengths, const float *img,
               const int32_t *labels, const nvqa_dropout *dropout, float *loss_out);
 
+/* Loss of the last step (waits for the stream). With loss_out == NULL nvqa_step only
+ * enqueues work; with a non-NULL loss_out it blocks like the reference's JdJ does. */
+int nvqa_get_loss(nvqa_ctx *ctx, float *loss_out);
+
 /* Evaluate-mode forward (all dropout = identity): scores [n x A] and/or
  * 1-based argmax [n] (either may be NULL), n <= B rows. */
 int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t *lengths,

@@ -1,0 +1,186 @@
+// epilogues.h -- fused GEMM epilogues of the VQA step (functors for gemm_f32.h).
+// Each one replaces a run of separate Torch7 pointwise modules; the reference line of the
+// module chain is cited at each functor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/nvqa_rng.h"
+
+namespace nvqa {
+
+struct Drop {
+    int mode;
+    float p, inv_keep;
+    uint64_t seed, step;
+    __device__ __forceinline__ float scale(uint32_t site, uint64_t idx) const
+    {
+        return mode ? nvqa_dropout_scale(seed, step, site, idx, p, inv_keep) : 1.0f;
+    }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanhf from libdevice is accurate to ~1 ulp; keep it (logit tolerance is 1e-4 relative)
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+
+// C[z][m][n] = v   (split-K partial slabs when gridDim.z > 1)
+struct EpiStore {
+    float *C;
+    int ldc;
+    size_t slab;
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v) const
+    {
+        C[(size_t)z * slab + (size_t)m * ldc + n] = v;
+    }
+};
+
+// nn.Linear bias add (two biases: b_i2h + b_h2h of misc/LSTM.lua:41-43 folded into the
+// time-batched i2h product)
+struct EpiBias2 {
+    float *C;
+    int ldc;
+    const float *b1, *b2;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        C[(size_t)m * ldc + n] = v + b1[n] + (b2 ? b2[n] : 0.0f);
+    }
+};
+
+// tanh(Linear(.)) -- misc/netdef.lua:10 (qc branch)
+struct EpiBiasTanh {
+    float *C;
+    int ldc;
+    const float *b;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        C[(size_t)m * ldc + n] = tanhf_(v + b[n]);
+    }
+};
+
+// ic = tanh(Linear(.)); z = qc (*) ic; zd = Dropout(z) -- netdef.lua:11-12, 002_train_baseline.lua:153
+struct EpiFuse {
+    float *ic, *zd;
+    const float *qc, *b;
+    int ldc;
+    Drop dr;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        const size_t o = (size_t)m * ldc + n;
+        const float i = tanhf_(v + b[n]);
+        ic[o] = i;
+        zd[o] = dr.scale(NVQA_SITE_Z, o) * (qc[o] * i);
+    }
+};
+
+// backward of Dropout -> CMulTable -> the two Tanh (netdef.lua:10-12): v = d(zd)
+struct EpiHeadBwd {
+    float *dqc, *dic;
+    const float *qc, *ic;
+    int ldc;
+    Drop dr;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        const size_t o = (size_t)m * ldc + n;
+        const float dz = dr.scale(NVQA_SITE_Z, o) * v;
+        const float q = qc[o], i = ic[o];
+        dqc[o] = dz * i * (1.0f - q * q);
+        dic[o] = dz * q * (1.0f - i * i);
+    }
+};
+
+// d(qd) -> Dropout backward -> re-sort into BPTT order and split into the per-layer
+// (c, h) state gradients: 002_train_baseline.lua:313 + misc/LSTM.lua:70 (JoinTable backward)
+struct EpiResort {
+    float *dC, *dH; // [L][B][R]
+    const int *sort_inv;
+    int B, R, Q;
+    Drop dr;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        const float s = dr.scale(NVQA_SITE_Q, (uint64_t)m * Q + n) * v;
+        const int r = sort_inv[m], l = n / (2 * R), part = (n / R) & 1, j = n % R;
+        float *dst = part ? dH : dC;
+        dst[((size_t)l * B + r) * R + j] = s;
+    }
+};
+
+// d(input of layer l) -> inter-layer Dropout backward (misc/LSTM.lua:37); rows are (t, r)
+struct EpiDU {
+    float *out; // [T*B][R]
+    const int *sort_idx;
+    int B, T, R, lm1; // lm1 = layer index - 1 (0-based layer l >= 1 -> l-1)
+    Drop dr;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        const int t = m / B, r = m % B;
+        const uint64_t idx = ((((uint64_t)lm1) * B + sort_idx[r]) * T + t) * R + n;
+        out[(size_t)m * R + n] = dr.scale(NVQA_SITE_LSTM, idx) * v;
+    }
+};
+
+// Fused LSTM cell forward (misc/LSTM.lua:43-59): a[4] = W_h2h h_{t-1} for gates (i,f,o,g);
+// gx holds W_i2h x_t + b_i2h + b_h2h on entry and the ACTIVATED gates on exit (kept for BPTT).
+// Rows >= *nrows have not started yet and keep a zero state (misc/RNNUtils.lua:136-145).
+struct EpiLstmFwd {
+    float *gx;           // [B][4R] of this step
+    const float *c_prev; // [B][R]
+    float *c, *h;        // [B][R]
+    float *u_next;       // optional [B][R]: Dropout(h) = input of the next layer at this step
+    const int *nrows, *sort_idx;
+    int R, B, T, t, lnext_m1; // lnext_m1 = (l+1)-1 = l for the dropout index of layer l+1
+    Drop dr;
+    __device__ __forceinline__ void operator()(int m, int u, const float (&a)[4]) const
+    {
+        const size_t gi = (size_t)m * 4 * R + u, si = (size_t)m * R + u;
+        if (m >= *nrows) {
+            gx[gi] = 0.f; gx[gi + R] = 0.f; gx[gi + 2 * R] = 0.f; gx[gi + 3 * R] = 0.f;
+            c[si] = 0.f; h[si] = 0.f;
+            if (u_next) u_next[si] = 0.f;
+            return;
+        }
+        const float ig = sigmoidf_(a[0] + gx[gi]);
+        const float fg = sigmoidf_(a[1] + gx[gi + R]);
+        const float og = sigmoidf_(a[2] + gx[gi + 2 * R]);
+        const float gg = tanhf_(a[3] + gx[gi + 3 * R]);
+        const float cn = fg * c_prev[si] + ig * gg;
+        const float hn = og * tanhf_(cn);
+        gx[gi] = ig; gx[gi + R] = fg; gx[gi + 2 * R] = og; gx[gi + 3 * R] = gg;
+        c[si] = cn; h[si] = hn;
+        if (u_next) {
+            const uint64_t idx = ((((uint64_t)lnext_m1) * B + sort_idx[m]) * T + t) * R + u;
+            u_next[si] = dr.scale(NVQA_SITE_LSTM, idx) * hn;
+        }
+    }
+};
+
+// Fused LSTM cell backward at step s (nngraph backward of misc/LSTM.lua:43-59, driven by
+// misc/RNNUtils.lua:182-209): v = (dG_{s+1} W_h2h)[m][u] is the recurrent part of dh_s.
+// gates holds the activated gates of step s on entry and d(pre-activations) on exit.
+struct EpiLstmBwd {
+    float *gates;              // [B][4R] of step s (in: i,f,o,g ; out: da)
+    const float *c_prev, *c;   // [B][R] cell before / after step s
+    float *dc;                 // [B][R] carried cell gradient (in: dL/dc_s from s+1, out: dL/dc_{s-1})
+    const float *dh_ext, *dh_ext2; // optional extra dL/dh_s terms (upper layer, head)
+    const int *nrows;
+    int R;
+    __device__ __forceinline__ void operator()(int, int m, int u, float v) const
+    {
+        const size_t gi = (size_t)m * 4 * R + u, si = (size_t)m * R + u;
+        if (m >= *nrows) { // gradient rows of not-yet-started questions are dropped (RNNUtils.lua:192-196)
+            gates[gi] = 0.f; gates[gi + R] = 0.f; gates[gi + 2 * R] = 0.f; gates[gi + 3 * R] = 0.f;
+            dc[si] = 0.f;
+            return;
+        }
+        float dh = v;
+        if (dh_ext) dh += dh_ext[si];
+        if (dh_ext2) dh += dh_ext2[si];
+        const float ig = gates[gi], fg = gates[gi + R], og = gates[gi + 2 * R], gg = gates[gi + 3 * R];
+        const float tc = tanhf_(c[si]);
+        const float dcv = dc[si] + dh * og * (1.0f - tc * tc);
+        gates[gi] = dcv * gg * ig * (1.0f - ig);
+        gates[gi + R] = dcv * c_prev[si] * fg * (1.0f - fg);
+        gates[gi + 2 * R] = dh * tc * og * (1.0f - og);
+        gates[gi + 3 * R] = dcv * ig * (1.0f - gg * gg);
+        dc[si] = dcv * fg;
+    }
+};
+
+} // namespace nvqa

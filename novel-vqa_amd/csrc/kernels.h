@@ -1,0 +1,337 @@
+// kernels.h -- the HBM-bound (non-GEMM) kernels of the VQA step: batch assembly,
+// embedding gather, head preparation, softmax cross-entropy, deterministic embedding
+// gradient, column sums, clamp+RMSprop.  64-wide wavefronts, coalesced 16-byte accesses
+// where the row width allows, no atomics on floats (results are bit-reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "epilogues.h"
+
+namespace nvqa {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// dataset:next_batch() gather (002_train_baseline.lua:202-210): rows qinds of the
+// HBM-resident dataset -> batch buffers.  One block per sample.
+// ---------------------------------------------------------------------------------
+__global__ void k_gather_batch(const int64_t *qinds, const int32_t *Q, const int32_t *QL,
+                               const int32_t *IP, const int32_t *ANS, const float *F, int T, int I,
+                               int32_t *tok, int32_t *len, int32_t *lab, float *img)
+{
+    const int b = blockIdx.x;
+    const int64_t q = qinds[b];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) tok[(size_t)b * T + t] = Q[q * T + t];
+    if (threadIdx.x == 0) {
+        len[b] = QL ? QL[q] : T;
+        lab[b] = ANS[q];
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(F + (size_t)(IP[q] - 1) * I);
+    float4 *dst = reinterpret_cast<float4 *>(img + (size_t)b * I);
+    for (int i = threadIdx.x; i < I / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// row L2 normalisation (002_train_baseline.lua:117-121), one wave per row, in place
+__global__ void k_l2norm_rows(float *F, int64_t n, int I)
+{
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float4 *p = reinterpret_cast<float4 *>(F + row * I);
+    float s = 0.f;
+    for (int i = lane; i < I / 4; i += 64) {
+        const float4 v = p[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = sqrtf(wave_sum(s));
+    for (int i = lane; i < I / 4; i += 64) {
+        float4 v = p[i];
+        v.x /= s; v.y /= s; v.z /= s; v.w /= s;
+        p[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sort_encoding_onehot_right_align (misc/RNNUtils.lua:84-124) without the one-hot:
+// stable descending counting sort of the lengths, inverse permutation, and the number of
+// active rows per time column.  Single workgroup (B is a few thousand at most).
+// ---------------------------------------------------------------------------------
+__global__ void k_sort_lengths(const int32_t *len, int B, int T, int32_t *sort_idx, int32_t *sort_inv,
+                               int32_t *nrows /*[T]*/)
+{
+    extern __shared__ int sm[]; // hist[T+1], start[T+1]
+    int *hist = sm, *start = sm + (T + 1);
+    for (int i = threadIdx.x; i <= T; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int l = min(max(len[b], 0), T);
+        atomicAdd(&hist[l], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int l = T; l >= 0; --l) { start[l] = acc; acc += hist[l]; }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int l = min(max(len[b], 0), T);
+        int rank = 0;
+        for (int c = 0; c < b; ++c) rank += (min(max(len[c], 0), T) == l);
+        const int pos = start[l] + rank;
+        sort_idx[pos] = b;
+        sort_inv[b] = pos;
+    }
+    // column t (0-based) is active for rows with len >= T - t
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        int n = 0;
+        for (int l = T - t; l <= T; ++l) n += hist[l];
+        nrows[t] = n;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// arch1 embedding forward: x = tanh(Dropout(W_e[:,tok] + b_e)) (002_train_baseline.lua:141-144).
+// The reference multiplies a dense one-hot [sum(len) x V] by W_e^T; every product but one per
+// row is an exact zero, so this is a row gather from the transposed table WeT [V][E].
+// One wave per packed row (t, r); writes zeros for inactive rows and records the token.
+// ---------------------------------------------------------------------------------
+__global__ void k_emb_fwd(const int32_t *tok, const int32_t *sort_idx, const int32_t *nrows,
+                          const float *WeT, const float *be, int B, int T, int E, Drop dr,
+                          float *X, int32_t *ptok)
+{
+    const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (row >= T * B) return;
+    const int t = row / B, r = row % B;
+    float4 *x4 = reinterpret_cast<float4 *>(X + (size_t)row * E);
+    if (r >= nrows[t]) {
+        for (int i = lane; i < E / 4; i += 64) x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) ptok[row] = -1;
+        return;
+    }
+    const int b = sort_idx[r];
+    const int w = tok[(size_t)b * T + t] - 1;
+    if (lane == 0) ptok[row] = w;
+    const float4 *w4 = reinterpret_cast<const float4 *>(WeT + (size_t)w * E);
+    const float4 *b4 = reinterpret_cast<const float4 *>(be);
+    const uint64_t base = ((uint64_t)b * T + t) * E;
+    for (int i = lane; i < E / 4; i += 64) {
+        const float4 wv = w4[i], bv = b4[i];
+        float4 o;
+        o.x = tanhf_(dr.scale(NVQA_SITE_EMB, base + 4 * i + 0) * (wv.x + bv.x));
+        o.y = tanhf_(dr.scale(NVQA_SITE_EMB, base + 4 * i + 1) * (wv.y + bv.y));
+        o.z = tanhf_(dr.scale(NVQA_SITE_EMB, base + 4 * i + 2) * (wv.z + bv.z));
+        o.w = tanhf_(dr.scale(NVQA_SITE_EMB, base + 4 * i + 3) * (wv.w + bv.w));
+        x4[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// head preparation: question vector [c1 h1 c2 h2 ...] un-sorted + Dropout
+// (002_train_baseline.lua:306, misc/LSTM.lua:70, netdef.lua:10) and Dropout on the
+// image feature (netdef.lua:11).  blockIdx.x = sample b.
+// ---------------------------------------------------------------------------------
+__global__ void k_head_prep(const float *Cfin /*[L][B][R]*/, const float *Hfin, size_t lstride,
+                            const int32_t *sort_inv, const float *img, int B, int R, int L, int I,
+                            Drop dr, float *qd, float *vd)
+{
+    const int b = blockIdx.x, r = sort_inv[b];
+    const int Q = 2 * R * L;
+    for (int j = threadIdx.x; j < Q; j += blockDim.x) {
+        const int l = j / (2 * R), part = (j / R) & 1, u = j % R;
+        const float *src = (part ? Hfin : Cfin) + (size_t)l * lstride + (size_t)r * R + u;
+        qd[(size_t)b * Q + j] = dr.scale(NVQA_SITE_Q, (uint64_t)b * Q + j) * (*src);
+    }
+    for (int j = threadIdx.x; j < I; j += blockDim.x)
+        vd[(size_t)b * I + j] = dr.scale(NVQA_SITE_V, (uint64_t)b * I + j) * img[(size_t)b * I + j];
+}
+
+// ---------------------------------------------------------------------------------
+// nn.CrossEntropyCriterion forward+backward in one pass (002_train_baseline.lua:157,308-310):
+// row max / sum in registers + wave shuffles, loss_b = lse - s[y], dscores = (softmax - onehot)/B.
+// One wave per row.  argmax (first maximal index, 1-based) optional.
+// ---------------------------------------------------------------------------------
+__global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, int A, float *dscores,
+                             float *rowloss, int32_t *argmax)
+{
+    const int b = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float *s = scores + (size_t)b * A;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int a = lane; a < A; a += 64) {
+        const float v = s[a];
+        if (v > mx) { mx = v; am = a; }
+    }
+    const float wmx = wave_max(mx);
+    if (argmax) {
+        int cand = (mx == wmx) ? am : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) argmax[b] = cand + 1;
+    }
+    if (!labels) return;
+    float sum = 0.f;
+    for (int a = lane; a < A; a += 64) sum += expf(s[a] - wmx);
+    sum = wave_sum(sum);
+    const float lse = wmx + logf(sum);
+    const int y = labels[b] - 1;
+    if (lane == 0) rowloss[b] = lse - s[y];
+    if (dscores) {
+        const float invB = 1.0f / (float)B;
+        for (int a = lane; a < A; a += 64)
+            dscores[(size_t)b * A + a] = (expf(s[a] - lse) - (a == y ? 1.0f : 0.0f)) * invB;
+    }
+}
+
+// mean of the row losses in a fixed order (single block -> bit-reproducible)
+__global__ void k_loss_mean(const float *rowloss, int B, float *loss)
+{
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) s += rowloss[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = part[0] / (float)B;
+}
+
+// ---------------------------------------------------------------------------------
+// column sums (bias gradients: nn.Linear accGradParameters, gradBias += colsum(dY)).
+// Stage 1: grid (N/64, S): block sums its row stripe for 64 columns -> part[s][n].
+// Stage 2: sums the S partials in order.  Deterministic.
+// ---------------------------------------------------------------------------------
+__global__ void k_colsum_part(const float *X, int M, int N, int ld, int rows_per_split, float *part)
+{
+    __shared__ float sm[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    float s = 0.f;
+    if (n < N)
+        for (int m = mbeg + w; m < mend; m += 4) s += X[(size_t)m * ld + n];
+    sm[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+__global__ void k_colsum_final(const float *part, int S, int N, float *out, float *out2)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(size_t)i * N + n];
+    out[n] = s;
+    if (out2) out2[n] = s;
+}
+
+// sum of split-K slabs (fixed order) with optional accumulate into C
+__global__ void k_reduce_slabs(const float *slabs, int S, size_t n4, float4 *C)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 *p = reinterpret_cast<const float4 *>(slabs);
+    float4 s = p[i];
+    for (int z = 1; z < S; ++z) {
+        const float4 v = p[(size_t)z * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    C[i] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// arch1 embedding backward (002_train_baseline.lua:319-320): d(pre) = Dropout' (tanh' dX);
+// dW_e[:,tok] += d(pre) summed in ascending packed order (bit-reproducible, no atomics).
+// Each wave owns 16 consecutive vocabulary rows, scans the packed token list once and
+// accumulates its rows in LDS; writes every row of its range (zeros included), so the
+// gradient table needs no memset.  The reference forms this as a dense
+// [E x sum(len)] x [sum(len) x V] GEMM over the one-hot matrix.
+// ---------------------------------------------------------------------------------
+#define NVQA_EB_ROWS 16
+__global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, const int32_t *sort_idx,
+                          int NP /*T*B*/, int B, int T, int V, int E, Drop dr, float *dWeT /*[V][E]*/)
+{
+    extern __shared__ float acc[]; // [waves][16][E]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    const int v0 = (blockIdx.x * waves + wave) * NVQA_EB_ROWS;
+    if (v0 >= V) return;
+    float *my = acc + (size_t)wave * NVQA_EB_ROWS * E;
+    for (int i = lane; i < NVQA_EB_ROWS * E; i += 64) my[i] = 0.f;
+    for (int k0 = 0; k0 < NP; k0 += 64) {
+        const int k = k0 + lane;
+        const int w = k < NP ? ptok[k] : -1;
+        unsigned long long hit = __ballot(w >= v0 && w < v0 + NVQA_EB_ROWS);
+        while (hit) {
+            const int src = __ffsll((long long)hit) - 1;
+            hit &= hit - 1;
+            const int kk = k0 + src;
+            const int row = __shfl(w, src, 64) - v0;
+            const int t = kk / B, r = kk % B;
+            const uint64_t base = ((uint64_t)sort_idx[r] * T + t) * E;
+            for (int e = lane; e < E; e += 64) {
+                const float x = X[(size_t)kk * E + e];
+                const float dp = dr.scale(NVQA_SITE_EMB, base + e) * (dX[(size_t)kk * E + e] * (1.0f - x * x));
+                my[row * E + e] += dp;
+            }
+        }
+    }
+    const int nr = min(NVQA_EB_ROWS, V - v0);
+    for (int i = lane; i < nr * E; i += 64) dWeT[(size_t)v0 * E + i] = my[i];
+}
+
+// ---------------------------------------------------------------------------------
+// gradients:clamp(-c,c) + optim.rmsprop in one pass (002_train_baseline.lua:329,408;
+// misc/rmsprop_lrscale.lua:16-34).  gscale = 1/world for the data-parallel mean.
+// 20 B/parameter of HBM traffic (read g,m,x; write m,x).
+// ---------------------------------------------------------------------------------
+__global__ void k_rmsprop(float4 *x, const float4 *g, float4 *m, size_t n4, float lr, float alpha,
+                          float eps, float wd, float clamp, float gscale)
+{
+    const float om = 1.0f - alpha;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float4 xv = x[i], gv = g[i], mv = m[i];
+        float *xp = &xv.x, *gp = &gv.x, *mp = &mv.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float gi = gp[c] * gscale;
+            if (clamp > 0.f) gi = fminf(fmaxf(gi, -clamp), clamp);
+            if (wd != 0.f) gi += wd * xp[c];
+            const float mi = alpha * mp[c] + om * gi * gi;
+            mp[c] = mi;
+            xp[c] += -lr * gi / (sqrtf(mi) + eps);
+        }
+        x[i] = xv;
+        m[i] = mv;
+    }
+}
+
+__global__ void k_clamp_copy(const float *g, float *out, size_t n, float clamp, float gscale)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = g[i] * gscale;
+        if (clamp > 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+        out[i] = v;
+    }
+}
+
+__global__ void k_fill(float *p, size_t n, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+} // namespace nvqa

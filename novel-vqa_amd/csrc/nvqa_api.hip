@@ -1,0 +1,850 @@
+// nvqa_api.hip -- the C ABI of include/nvqa.h: context, parameter I/O, and the
+// orchestration of the training step (forward, backward, update) as launches of the
+// gfx950 kernels in gemm_f32.h / kernels.h on one HIP stream.
+//
+// Reference call stack being replaced: optim.rmsprop -> JdJ
+// (002_train_vqa_arch1/002_train_baseline.lua:272-335,408).
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "gemm_f32.h"
+#include "kernels.h"
+#include "nvqa_ctx.h"
+
+using namespace nvqa;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+namespace nvqa {
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+} // namespace nvqa
+extern "C" const char *nvqa_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------
+// profiling scope: brackets the launches of one group with HIP events on ctx->s
+// ------------------------------------------------------------------------------------
+static const char *kProfNames[PF_COUNT] = {
+    "assemble",      "emb_fwd",       "gemm_i2h_fwd", "lstm_step_fwd", "head_prep", "gemm_head_fwd",
+    "softmax_ce",    "gemm_head_bwd", "lstm_step_bwd", "gemm_dgrad",   "gemm_wgrad", "reduce_slabs",
+    "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch"};
+
+struct ProfScope {
+    nvqa_ctx *c;
+    int id;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(nvqa_ctx *c_, int id_, double flops = 0, double bytes = 0) : c(c_), id(id_)
+    {
+        if (!c->prof_on) return;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, c->s);
+        c->prof[id].flops += flops;
+        c->prof[id].bytes += bytes;
+        c->prof[id].launches += 1;
+    }
+    ~ProfScope()
+    {
+        if (!c->prof_on) return;
+        hipEventRecord(e1, c->s);
+        c->prof[id].pending.emplace_back(e0, e1);
+    }
+};
+
+static void prof_collect(nvqa_ctx *c)
+{
+    for (int i = 0; i < PF_COUNT; ++i) {
+        for (auto &p : c->prof[i].pending) {
+            float ms = 0;
+            hipEventSynchronize(p.second);
+            hipEventElapsedTime(&ms, p.first, p.second);
+            c->prof[i].ms += ms;
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        c->prof[i].pending.clear();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// GEMM configurations (tile shapes; see DESIGN.md "Kernels")
+// ------------------------------------------------------------------------------------
+// BIG : 128x128x32 block, 4 waves of 64x64 (2x2 MFMA 32x32x2 tiles)  -- time-batched products
+// MED : 64x64x32 block, 4 waves of 32x32                              -- M = B products of the head
+// LSTM forward step : 32 rows x 32 units x 4 gates, MFMA 16x16x4, fused cell
+// LSTM backward step: 32x32, MFMA 16x16x4, fused cell backward
+template <int AM, int BMo, class Epi>
+static int gemm_big(nvqa_ctx *c, const GemmArgs &g, const Epi &e)
+{
+    NVQA_HIP((launch_gemm<32, 128, 128, 32, 2, 2, AM, BMo, false, Epi>(c->s, g, e)));
+    return 0;
+}
+template <int AM, int BMo, class Epi>
+static int gemm_med(nvqa_ctx *c, const GemmArgs &g, const Epi &e)
+{
+    NVQA_HIP((launch_gemm<32, 64, 64, 32, 2, 2, AM, BMo, false, Epi>(c->s, g, e)));
+    return 0;
+}
+
+static GemmArgs mkargs(const float *A, int lda, const float *B, int ldb, int M, int N, int K,
+                       int kslice = 0, int R = 0, const int *mlimit = nullptr)
+{
+    GemmArgs g;
+    g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.kslice = kslice > 0 ? kslice : (K > 0 ? K : 1);
+    g.R = R; g.mlimit = mlimit;
+    return g;
+}
+
+static inline Drop mkdrop(const nvqa_dropout *dr, bool train)
+{
+    Drop d;
+    if (!train || !dr || dr->mode == 0) {
+        d.mode = 0; d.p = 0.f; d.inv_keep = 1.f; d.seed = 0; d.step = 0;
+    } else {
+        d.mode = 1; d.p = dr->p; d.inv_keep = 1.0f / (1.0f - dr->p); d.seed = dr->seed; d.step = dr->step;
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------
+template <class T> static int dalloc(T **p, size_t n)
+{
+    NVQA_HIP(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+static int check_dims(const nvqa_dims *d)
+{
+    if (!d) { set_error("dims is NULL"); return -1; }
+    if (d->arch != NVQA_ARCH1 && d->arch != NVQA_ARCH2) { set_error("arch must be 1 or 2"); return -1; }
+    if (d->B < 1 || d->T < 1 || d->V < 1 || d->L < 1 || d->L > NVQA_MAX_LAYERS) {
+        set_error("bad dims (B=%d T=%d V=%d L=%d)", d->B, d->T, d->V, d->L);
+        return -1;
+    }
+    // 16-byte vector accesses: every row width must be a multiple of 4 floats
+    if (d->E % 4 || d->R % 4 || d->I % 4 || d->A % 4 || (d->arch == NVQA_ARCH1 && d->C % 4)) {
+        set_error("E, R, I, C, A must be multiples of 4 (got E=%d R=%d I=%d C=%d A=%d)", d->E, d->R,
+                  d->I, d->C, d->A);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
+{
+    if (!out) { set_error("out is NULL"); return -1; }
+    *out = nullptr;
+    NVQA_TRY(check_dims(dims));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device available (libnvqa has no CPU fallback)");
+        return -2;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return -1; }
+    NVQA_HIP(hipSetDevice(device));
+    nvqa_ctx *c = new nvqa_ctx();
+    c->d = *dims;
+    c->device = device;
+    if (nvqa_layout_init(dims, &c->lo)) { delete c; set_error("layout"); return -1; }
+    const nvqa_dims &d = c->d;
+    c->TS = d.arch == NVQA_ARCH1 ? d.T : d.T + 2;
+    const size_t B = d.B, R = d.R, E = d.E, L = d.L, TS = c->TS, TB = TS * B;
+    NVQA_HIP(hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking));
+    NVQA_TRY(dalloc(&c->P, c->lo.total));
+    NVQA_TRY(dalloc(&c->G, c->lo.total));
+    NVQA_TRY(dalloc(&c->M2, c->lo.total));
+    NVQA_HIP(hipMemsetAsync(c->P, 0, c->lo.total * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->G, 0, c->lo.total * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->M2, 0, c->lo.total * 4, c->s));
+    NVQA_TRY(dalloc(&c->tok, B * d.T));
+    NVQA_TRY(dalloc(&c->len, B));
+    NVQA_TRY(dalloc(&c->lab, B));
+    NVQA_TRY(dalloc(&c->img, B * d.I));
+    NVQA_TRY(dalloc(&c->qinds, B));
+    NVQA_TRY(dalloc(&c->sort_idx, B));
+    NVQA_TRY(dalloc(&c->sort_inv, B));
+    NVQA_TRY(dalloc(&c->nrows, TS));
+    NVQA_TRY(dalloc(&c->ptok, TB));
+    NVQA_TRY(dalloc(&c->X0, TB * E));
+    NVQA_TRY(dalloc(&c->dX0, TB * E));
+    for (size_t l = 0; l < L; ++l) {
+        NVQA_TRY(dalloc(&c->Gt[l], TB * 4 * R));
+        if (l == 0) { // one allocation for all layers: [L][(TS+1)*B][R]
+            NVQA_TRY(dalloc(&c->Hs[0], L * (TS + 1) * B * R));
+            NVQA_TRY(dalloc(&c->Cs[0], L * (TS + 1) * B * R));
+            NVQA_HIP(hipMemsetAsync(c->Hs[0], 0, L * (TS + 1) * B * R * 4, c->s)); // step-0 state stays zero
+            NVQA_HIP(hipMemsetAsync(c->Cs[0], 0, L * (TS + 1) * B * R * 4, c->s));
+        } else {
+            c->Hs[l] = c->Hs[0] + l * (TS + 1) * B * R;
+            c->Cs[l] = c->Cs[0] + l * (TS + 1) * B * R;
+        }
+        if (l > 0) NVQA_TRY(dalloc(&c->U[l], TB * R));
+        if (l + 1 < L) NVQA_TRY(dalloc(&c->dHext[l], TB * R));
+    }
+    NVQA_TRY(dalloc(&c->dCT, L * B * R));
+    NVQA_TRY(dalloc(&c->dHT, L * B * R));
+    const size_t Q = d.arch == NVQA_ARCH1 ? 2 * R * L : R, C = d.arch == NVQA_ARCH1 ? d.C : 0;
+    NVQA_TRY(dalloc(&c->qd, B * Q));
+    NVQA_TRY(dalloc(&c->vd, B * d.I));
+    NVQA_TRY(dalloc(&c->qc, B * C));
+    NVQA_TRY(dalloc(&c->ic, B * C));
+    NVQA_TRY(dalloc(&c->zd, B * C));
+    NVQA_TRY(dalloc(&c->dqc, B * std::max(C, R)));
+    NVQA_TRY(dalloc(&c->dic, B * C));
+    NVQA_TRY(dalloc(&c->scores, B * d.A));
+    NVQA_TRY(dalloc(&c->dscores, B * d.A));
+    NVQA_TRY(dalloc(&c->rowloss, B));
+    NVQA_TRY(dalloc(&c->d_loss, 1));
+    NVQA_TRY(dalloc(&c->argmax, B));
+    // scratch: column-sum partials (64 splits x widest matrix) and split-K slabs
+    const size_t widest = std::max<size_t>(std::max<size_t>(4 * R, d.I), std::max<size_t>(d.A, std::max<size_t>(E, C)));
+    NVQA_TRY(dalloc(&c->colpart, 64 * widest));
+    c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
+    NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
+    NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
+    *c->h_loss = 0.f;
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    *out = c;
+    return 0;
+}
+
+extern "C" int nvqa_destroy(nvqa_ctx *c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->s);
+    prof_collect(c);
+    void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
+                    c->nrows, c->ptok, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
+                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs,
+                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    for (int l = 0; l < NVQA_MAX_LAYERS; ++l) {
+        if (c->Gt[l]) hipFree(c->Gt[l]);
+        if (l == 0 && c->Hs[l]) hipFree(c->Hs[l]);
+        if (l == 0 && c->Cs[l]) hipFree(c->Cs[l]);
+        if (c->U[l]) hipFree(c->U[l]);
+        if (c->dHext[l]) hipFree(c->dHext[l]);
+    }
+    if (c->h_loss) hipHostFree(c->h_loss);
+    if (c->s) hipStreamDestroy(c->s);
+    delete c;
+    return 0;
+}
+
+extern "C" int nvqa_sync(nvqa_ctx *c)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// parameters
+// ------------------------------------------------------------------------------------
+extern "C" size_t nvqa_param_count(const nvqa_ctx *c) { return c ? c->lo.total : 0; }
+
+extern "C" int nvqa_segments(const nvqa_ctx *c, size_t out[3])
+{
+    if (!c || !out) { set_error("NULL argument"); return -1; }
+    out[0] = c->lo.seg[0]; out[1] = c->lo.seg[1]; out[2] = c->lo.seg[2];
+    return 0;
+}
+
+// ABI layout <-> internal layout: only the arch1 embedding weight differs
+// (Torch nn.Linear [E][V] at the ABI, gather-friendly [V][E] on the device).
+static void to_internal(const nvqa_ctx *c, const float *abi, std::vector<float> &in)
+{
+    in.assign(abi, abi + c->lo.total);
+    if (c->d.arch == NVQA_ARCH1) {
+        const size_t E = c->d.E, V = c->d.V;
+        const float *src = abi + c->lo.w_e;
+        float *dst = in.data() + c->lo.w_e;
+        for (size_t e = 0; e < E; ++e)
+            for (size_t v = 0; v < V; ++v) dst[v * E + e] = src[e * V + v];
+    }
+}
+static void to_abi(const nvqa_ctx *c, const std::vector<float> &in, float *abi)
+{
+    memcpy(abi, in.data(), c->lo.total * sizeof(float));
+    if (c->d.arch == NVQA_ARCH1) {
+        const size_t E = c->d.E, V = c->d.V;
+        const float *src = in.data() + c->lo.w_e;
+        float *dst = abi + c->lo.w_e;
+        for (size_t v = 0; v < V; ++v)
+            for (size_t e = 0; e < E; ++e) dst[e * V + v] = src[v * E + e];
+    }
+}
+
+extern "C" int nvqa_set_params(nvqa_ctx *c, const float *params)
+{
+    if (!c || !params) { set_error("NULL argument"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    std::vector<float> in;
+    to_internal(c, params, in);
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    NVQA_HIP(hipMemcpy(c->P, in.data(), c->lo.total * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int nvqa_get_params(nvqa_ctx *c, float *out)
+{
+    if (!c || !out) { set_error("NULL argument"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    std::vector<float> in(c->lo.total);
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    NVQA_HIP(hipMemcpy(in.data(), c->P, c->lo.total * 4, hipMemcpyDeviceToHost));
+    to_abi(c, in, out);
+    return 0;
+}
+
+extern "C" int nvqa_init_params(nvqa_ctx *c, uint64_t seed, float lo, float hi)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    // *_w:uniform(-0.08, 0.08) over each flat segment (002_train_baseline.lua:174-181);
+    // counter-based so that every rank of a data-parallel job draws the same values.
+    std::vector<float> p(c->lo.total);
+    for (size_t i = 0; i < p.size(); ++i) {
+        const float u = (float)(nvqa_hash32(seed, 0, 99u, i) >> 8) * (1.0f / 16777216.0f);
+        p[i] = lo + (hi - lo) * u;
+    }
+    NVQA_TRY(nvqa_set_params(c, p.data()));
+    NVQA_HIP(hipMemset(c->M2, 0, c->lo.total * 4));
+    return 0;
+}
+
+static int allreduce_grads(nvqa_ctx *c); // below
+
+extern "C" int nvqa_get_grads(nvqa_ctx *c, float *out, float clamp)
+{
+    if (!c || !out) { set_error("NULL argument"); return -1; }
+    if (!c->have_grads) { set_error("nvqa_get_grads before any nvqa_step"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    std::vector<float> in(c->lo.total);
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    NVQA_HIP(hipMemcpy(in.data(), c->G, c->lo.total * 4, hipMemcpyDeviceToHost));
+    if (clamp > 0.f)
+        for (float &v : in) v = std::min(std::max(v, -clamp), clamp);
+    to_abi(c, in, out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// helpers: bias gradient = column sum, split-K wgrad
+// ------------------------------------------------------------------------------------
+static int colsum(nvqa_ctx *c, const float *X, int M, int N, int ld, float *out, float *out2)
+{
+    ProfScope ps(c, PF_COLSUM, 0, (double)M * N * 4);
+    int S = std::min(64, std::max(1, M / 64));
+    const int rps = (M + S - 1) / S;
+    S = (M + rps - 1) / rps;
+    hipLaunchKernelGGL(k_colsum_part, dim3((N + 63) / 64, S), dim3(256), 0, c->s, X, M, N, ld, rps, c->colpart);
+    hipLaunchKernelGGL(k_colsum_final, dim3((N + 255) / 256), dim3(256), 0, c->s, c->colpart, S, N, out, out2);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+// dW[M x N] = A^T B with A stored [K][M], B stored [K][N]; K = TS*B is long, the output
+// small: split K over blockIdx.z into slabs, then sum the slabs in order (deterministic).
+static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb, int M, int N, int K,
+                 float *dW)
+{
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int ks = 1;
+    while (ks < 8 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2;
+    if ((size_t)ks * M * N > c->slab_floats) ks = std::max<int>(1, (int)(c->slab_floats / ((size_t)M * N)));
+    int kslice = (K + ks - 1) / ks;
+    kslice = (kslice + 31) / 32 * 32;
+    ks = (K + kslice - 1) / kslice;
+    {
+        ProfScope ps(c, PF_GEMM_WGRAD, 2.0 * M * N * K, ((double)K * (M + N) + (double)ks * M * N) * 4);
+        GemmArgs g = mkargs(A, lda, Bm, ldb, M, N, K, kslice);
+        if (ks == 1) {
+            NVQA_TRY((gemm_big<A_MC, B_NC>(c, g, EpiStore{dW, N, 0})));
+            return 0;
+        }
+        NVQA_TRY((gemm_big<A_MC, B_NC>(c, g, EpiStore{c->slabs, N, (size_t)M * N})));
+    }
+    ProfScope ps(c, PF_REDUCE, 0, (double)(ks + 1) * M * N * 4);
+    const size_t n4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n4 + 255) / 256), dim3(256), 0, c->s, c->slabs, ks, n4,
+                       reinterpret_cast<float4 *>(dW));
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// LSTM: shared by arch1 and arch2 (misc/LSTM.lua, misc/LSTM_encoder.lua have the same cell)
+// X0 [TS*B][E] holds the layer-0 inputs; nrows[t] rows are active at step t.
+// ------------------------------------------------------------------------------------
+static int lstm_forward(nvqa_ctx *c, const Drop &dr)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
+    for (int l = 0; l < L; ++l) {
+        const int in = l == 0 ? d.E : R;
+        const float *Xin = l == 0 ? c->X0 : c->U[l];
+        {   // time-batched input projection + both biases (LSTM.lua:41-43)
+            ProfScope ps(c, PF_GEMM_I2H, 2.0 * TB * 4 * R * in, ((double)TB * (in + 4 * R) + 4.0 * R * in) * 4);
+            GemmArgs g = mkargs(Xin, in, c->P + c->lo.w_i2h[l], in, TB, 4 * R, in);
+            NVQA_TRY((gemm_big<A_KC, B_KC>(c, g, EpiBias2{c->Gt[l], 4 * R, c->P + c->lo.b_i2h[l], c->P + c->lo.b_h2h[l]})));
+        }
+        for (int t = 0; t < TS; ++t) {
+            ProfScope ps(c, PF_LSTM_FWD, 2.0 * B * 4 * R * R, ((double)B * R * 4 + 4.0 * R * R + (double)B * 4 * R * 2) * 4);
+            EpiLstmFwd e;
+            e.gx = c->Gt[l] + (size_t)t * B * 4 * R;
+            e.c_prev = c->Cs[l] + (size_t)t * B * R;
+            e.c = c->Cs[l] + (size_t)(t + 1) * B * R;
+            e.h = c->Hs[l] + (size_t)(t + 1) * B * R;
+            e.u_next = l + 1 < L ? c->U[l + 1] + (size_t)t * B * R : nullptr;
+            e.nrows = c->nrows + t;
+            e.sort_idx = c->sort_idx;
+            e.R = R; e.B = B; e.T = TS; e.t = t; e.lnext_m1 = l;
+            e.dr = dr;
+            // step 0: h_{-1} = 0, the product vanishes (K = 0 skips the main loop)
+            GemmArgs g = mkargs(c->Hs[l] + (size_t)t * B * R, R, c->P + c->lo.w_h2h[l], R, B, R, t == 0 ? 0 : R, 0, R, c->nrows + t);
+            NVQA_HIP((launch_gemm<16, 32, 128, 32, 2, 2, A_KC, B_KC, true, EpiLstmFwd>(c->s, g, e)));
+        }
+    }
+    return 0;
+}
+
+// BPTT.  On entry dCT/dHT [L][B][R] hold dL/d(final c, h) per layer (sorted row order).
+// On exit Gt[l] holds d(pre-activations) for every step, G holds the LSTM weight gradients,
+// and (want_dx0) dX0 holds dL/d(layer-0 input).
+static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
+    for (int l = L - 1; l >= 0; --l) {
+        const int in = l == 0 ? d.E : R;
+        float *dcarry = c->dCT + (size_t)l * B * R;
+        for (int s = TS - 1; s >= 0; --s) {
+            ProfScope ps(c, PF_LSTM_BWD, s == TS - 1 ? 0.0 : 2.0 * B * 4 * R * R,
+                         ((double)B * 4 * R * 3 + 4.0 * R * R + (double)B * R * 5) * 4);
+            EpiLstmBwd e;
+            e.gates = c->Gt[l] + (size_t)s * B * 4 * R;
+            e.c_prev = c->Cs[l] + (size_t)s * B * R;
+            e.c = c->Cs[l] + (size_t)(s + 1) * B * R;
+            e.dc = dcarry;
+            e.dh_ext = l + 1 < L ? c->dHext[l] + (size_t)s * B * R : nullptr;
+            e.dh_ext2 = s == TS - 1 ? c->dHT + (size_t)l * B * R : nullptr;
+            e.nrows = c->nrows + s;
+            e.R = R;
+            // dh_s(recurrent) = dG_{s+1} W_h2h ; at the last step there is no successor (K = 0)
+            const float *A = s == TS - 1 ? c->Gt[l] : c->Gt[l] + (size_t)(s + 1) * B * 4 * R;
+            GemmArgs g = mkargs(A, 4 * R, c->P + c->lo.w_h2h[l], R, B, R, s == TS - 1 ? 0 : 4 * R, 0, 0, c->nrows + s);
+            NVQA_HIP((launch_gemm<16, 32, 32, 32, 2, 2, A_KC, B_NC, false, EpiLstmBwd>(c->s, g, e)));
+        }
+        // weight gradients, summed over all steps (002_train_baseline.lua:323-326)
+        const float *Xin = l == 0 ? c->X0 : c->U[l];
+        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l]));
+        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l]));
+        NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l]));
+        // d(layer input)
+        if (l > 0) {
+            ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * R * 4 * R, ((double)TB * 5 * R + 4.0 * R * R) * 4);
+            GemmArgs g = mkargs(c->Gt[l], 4 * R, c->P + c->lo.w_i2h[l], R, TB, R, 4 * R);
+            NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiDU{c->dHext[l - 1], c->sort_idx, B, TS, R, l - 1, dr})));
+        } else if (dX0) {
+            ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
+            GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
+            NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiStore{dX0, d.E, 0})));
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// arch1
+// ------------------------------------------------------------------------------------
+static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argmax)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, T = d.T, R = d.R, L = d.L, E = d.E, I = d.I, C = d.C, A = d.A, Q = 2 * R * L;
+    const int TB = T * B;
+    {
+        ProfScope ps(c, PF_ASSEMBLE);
+        hipLaunchKernelGGL(k_sort_lengths, dim3(1), dim3(1024), (2 * (T + 1)) * sizeof(int), c->s, c->len, B, T,
+                           c->sort_idx, c->sort_inv, c->nrows);
+    }
+    {
+        ProfScope ps(c, PF_EMB_FWD, 0, 2.0 * TB * E * 4);
+        hipLaunchKernelGGL(k_emb_fwd, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->sort_idx, c->nrows,
+                           c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok);
+    }
+    NVQA_HIP(hipGetLastError());
+    NVQA_TRY(lstm_forward(c, dr));
+    {
+        ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * (Q + I) * 4);
+        hipLaunchKernelGGL(k_head_prep, dim3(B), dim3(256), 0, c->s, c->Cs[0] + (size_t)T * B * R,
+                           c->Hs[0] + (size_t)T * B * R, (size_t)(T + 1) * B * R, c->sort_inv, c->img, B, R, L, I, dr, c->qd, c->vd);
+    }
+    NVQA_HIP(hipGetLastError());
+    {
+        ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * ((double)C * Q + (double)C * I + (double)A * C),
+                     ((double)C * Q + (double)C * I + (double)A * C) * 4);
+        // qc = tanh(W_q Dropout(q) + b_q)
+        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q),
+                                       EpiBiasTanh{c->qc, C, c->P + c->lo.b_q})));
+        // ic = tanh(W_v Dropout(v) + b_v); zd = Dropout(qc (*) ic)
+        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I),
+                                       EpiFuse{c->ic, c->zd, c->qc, c->P + c->lo.b_v, C, dr})));
+        // scores = W_o zd + b_o
+        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->zd, C, c->P + c->lo.w_o, C, B, A, C),
+                                       EpiBias2{c->scores, A, c->P + c->lo.b_o, nullptr})));
+    }
+    {
+        ProfScope ps(c, PF_SOFTMAX_CE, 0, 2.0 * B * A * 4);
+        hipLaunchKernelGGL(k_softmax_ce, dim3((B + 3) / 4), dim3(256), 0, c->s, c->scores,
+                           train ? c->lab : (const int32_t *)nullptr, B, A, train ? c->dscores : (float *)nullptr,
+                           c->rowloss, want_argmax ? c->argmax : (int32_t *)nullptr);
+        if (train) hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(256), 0, c->s, c->rowloss, B, c->d_loss);
+    }
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+static int arch1_backward(nvqa_ctx *c, const Drop &dr)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, T = d.T, R = d.R, L = d.L, E = d.E, I = d.I, C = d.C, A = d.A, Q = 2 * R * L;
+    const int TB = T * B, V = d.V;
+    float *G = c->G;
+    {
+        ProfScope ps(c, PF_GEMM_HEAD_BWD,
+                     2.0 * B * (2.0 * A * C + 2.0 * C * Q + (double)C * I),
+                     (2.0 * A * C + 2.0 * C * Q + 2.0 * C * I) * 4);
+        // classifier: dW_o = dscores^T zd ; d(zd) = dscores W_o -> Dropout', CMul', Tanh'
+        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, C, A, C, B), EpiStore{G + c->lo.w_o, C, 0})));
+        NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, C, B, C, A),
+                                       EpiHeadBwd{c->dqc, c->dic, c->qc, c->ic, C, dr})));
+        // fusion: dW_q = dqc^T qd ; dW_v = dic^T vd ; d(qd) = dqc W_q (no gradient to the image)
+        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dqc, C, c->qd, Q, C, Q, B), EpiStore{G + c->lo.w_q, Q, 0})));
+        NVQA_TRY((gemm_big<A_MC, B_NC>(c, mkargs(c->dic, C, c->vd, I, C, I, B), EpiStore{G + c->lo.w_v, I, 0})));
+        NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dqc, C, c->P + c->lo.w_q, Q, B, Q, C),
+                                       EpiResort{c->dCT, c->dHT, c->sort_inv, B, R, Q, dr})));
+    }
+    NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
+    NVQA_TRY(colsum(c, c->dqc, B, C, C, G + c->lo.b_q, nullptr));
+    NVQA_TRY(colsum(c, c->dic, B, C, C, G + c->lo.b_v, nullptr));
+    float *dX0 = c->dX0;
+    NVQA_TRY(lstm_backward(c, dr, dX0));
+    {
+        ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
+        const int waves = 4;
+        const int blocks = (V + waves * NVQA_EB_ROWS - 1) / (waves * NVQA_EB_ROWS);
+        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
+                           c->ptok, c->X0, dX0, c->sort_idx, TB, B, T, V, E, dr, G + c->lo.w_e);
+    }
+    NVQA_HIP(hipGetLastError());
+    NVQA_TRY(colsum(c, G + c->lo.w_e, V, E, E, G + c->lo.b_e, nullptr));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// the step
+// ------------------------------------------------------------------------------------
+static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
+{
+    const Drop dr = mkdrop(dropout, true);
+    if (c->d.arch == NVQA_ARCH1) {
+        NVQA_TRY(arch1_forward(c, dr, true, false));
+        NVQA_TRY(arch1_backward(c, dr));
+    } else {
+        set_error("arch2 step is not built yet");
+        return -3;
+    }
+    c->have_grads = true;
+    NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
+    if (loss_out) {
+        NVQA_HIP(hipStreamSynchronize(c->s));
+        *loss_out = *c->h_loss;
+    }
+    return 0;
+}
+
+static int upload_batch(nvqa_ctx *c, int n, const int32_t *tokens, const int32_t *lengths, const float *img,
+                        const int32_t *labels)
+{
+    const nvqa_dims &d = c->d;
+    const size_t B = d.B, T = d.T, I = d.I;
+    if (n < 1 || n > d.B) { set_error("batch rows %d outside 1..%d", n, d.B); return -1; }
+    if (!tokens || !img || (d.arch == NVQA_ARCH1 && !lengths)) { set_error("NULL batch pointer"); return -1; }
+    // validate on the host: a bad index would fault on the device
+    std::vector<int32_t> tk(B * T), ln(B), lb(B, 1);
+    std::vector<float> im;
+    for (size_t b = 0; b < B; ++b) {
+        const size_t sb = b < (size_t)n ? b : 0; // short eval batches are padded with row 0
+        const int32_t l = lengths ? lengths[sb] : (int32_t)T;
+        if (d.arch == NVQA_ARCH1 && (l < 1 || l > (int32_t)T)) { set_error("length[%zu]=%d outside 1..%zu", sb, l, T); return -1; }
+        ln[b] = l;
+        for (size_t t = 0; t < T; ++t) {
+            const int32_t w = tokens[sb * T + t];
+            const bool pad = d.arch == NVQA_ARCH1 ? t < T - (size_t)l : false;
+            if (pad ? w != 0 : (d.arch == NVQA_ARCH1 ? (w < 1 || w > d.V) : (w < 0 || w > d.V))) {
+                set_error("token[%zu][%zu]=%d invalid (V=%d, length=%d)", sb, t, w, d.V, l);
+                return -1;
+            }
+            tk[b * T + t] = w;
+        }
+        if (labels) {
+            if (labels[sb] < 1 || labels[sb] > d.A) { set_error("label[%zu]=%d outside 1..%d", sb, labels[sb], d.A); return -1; }
+            lb[b] = labels[sb];
+        }
+    }
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    NVQA_HIP(hipMemcpy(c->tok, tk.data(), B * T * 4, hipMemcpyHostToDevice));
+    NVQA_HIP(hipMemcpy(c->len, ln.data(), B * 4, hipMemcpyHostToDevice));
+    NVQA_HIP(hipMemcpy(c->lab, lb.data(), B * 4, hipMemcpyHostToDevice));
+    if ((size_t)n == B) {
+        NVQA_HIP(hipMemcpy(c->img, img, B * I * 4, hipMemcpyHostToDevice));
+    } else {
+        im.resize(B * I);
+        for (size_t b = 0; b < B; ++b) memcpy(&im[b * I], img + (b < (size_t)n ? b : 0) * I, I * 4);
+        NVQA_HIP(hipMemcpy(c->img, im.data(), B * I * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int nvqa_step(nvqa_ctx *c, const int32_t *tokens, const int32_t *lengths, const float *img,
+                         const int32_t *labels, const nvqa_dropout *dropout, float *loss_out)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    if (!labels) { set_error("labels is NULL"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_TRY(upload_batch(c, c->d.B, tokens, lengths, img, labels));
+    return run_step(c, dropout, loss_out);
+}
+
+extern "C" int nvqa_forward(nvqa_ctx *c, int32_t n, const int32_t *tokens, const int32_t *lengths,
+                            const float *img, float *scores_out, int32_t *argmax_out)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_TRY(upload_batch(c, n, tokens, lengths, img, nullptr));
+    const Drop dr = mkdrop(nullptr, false);
+    if (c->d.arch == NVQA_ARCH1) {
+        NVQA_TRY(arch1_forward(c, dr, false, true));
+    } else {
+        set_error("arch2 forward is not built yet");
+        return -3;
+    }
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    if (scores_out) NVQA_HIP(hipMemcpy(scores_out, c->scores, (size_t)n * c->d.A * 4, hipMemcpyDeviceToHost));
+    if (argmax_out) NVQA_HIP(hipMemcpy(argmax_out, c->argmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nvqa_get_loss(nvqa_ctx *c, float *loss_out)
+{
+    if (!c || !loss_out) { set_error("NULL argument"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    *loss_out = *c->h_loss;
+    return 0;
+}
+
+extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps, float wd, float clamp)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    if (!c->have_grads) { set_error("nvqa_rmsprop_update before any nvqa_step"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_TRY(allreduce_grads(c));
+    ProfScope ps(c, PF_RMSPROP, 0, 20.0 * c->lo.total);
+    const size_t n4 = c->lo.total / 4; // every tensor size is a multiple of 4 (check_dims)
+    hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
+                       reinterpret_cast<const float4 *>(c->G), reinterpret_cast<float4 *>(c->M2), n4, lr, alpha,
+                       eps, wd, clamp, 1.0f / (float)c->world);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// HBM-resident dataset + device-side next_batch
+// ------------------------------------------------------------------------------------
+extern "C" int nvqa_dataset_load(nvqa_ctx *c, int64_t n_q, const int32_t *questions, const int32_t *lengths,
+                                 const int32_t *img_pos, const int32_t *answers, int64_t n_img,
+                                 const float *feats, int l2_normalize)
+{
+    if (!c || !questions || !img_pos || !answers || !feats) { set_error("NULL argument"); return -1; }
+    if (n_q < 1 || n_img < 1) { set_error("empty dataset"); return -1; }
+    const nvqa_dims &d = c->d;
+    if (d.arch == NVQA_ARCH1 && !lengths) { set_error("arch1 needs lengths"); return -1; }
+    for (int64_t q = 0; q < n_q; ++q) {
+        if (img_pos[q] < 1 || img_pos[q] > n_img) { set_error("img_pos[%lld]=%d outside 1..%lld", (long long)q, img_pos[q], (long long)n_img); return -1; }
+        if (answers[q] < 1 || answers[q] > d.A) { set_error("answers[%lld]=%d outside 1..%d", (long long)q, answers[q], d.A); return -1; }
+        const int l = lengths ? lengths[q] : d.T;
+        if (d.arch == NVQA_ARCH1 && (l < 1 || l > d.T)) { set_error("lengths[%lld]=%d outside 1..%d", (long long)q, l, d.T); return -1; }
+        for (int t = 0; t < d.T; ++t) {
+            const int w = questions[q * d.T + t];
+            const bool pad = d.arch == NVQA_ARCH1 && t < d.T - l;
+            if (pad ? w != 0 : (d.arch == NVQA_ARCH1 ? (w < 1 || w > d.V) : (w < 0 || w > d.V))) {
+                set_error("questions[%lld][%d]=%d invalid", (long long)q, t, w);
+                return -1;
+            }
+        }
+    }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    Dataset &ds = c->ds;
+    for (void *p : {(void *)ds.Q, (void *)ds.QL, (void *)ds.IP, (void *)ds.ANS, (void *)ds.F})
+        if (p) hipFree(p);
+    ds = Dataset();
+    NVQA_TRY(dalloc(&ds.Q, (size_t)n_q * d.T));
+    NVQA_TRY(dalloc(&ds.IP, (size_t)n_q));
+    NVQA_TRY(dalloc(&ds.ANS, (size_t)n_q));
+    NVQA_TRY(dalloc(&ds.F, (size_t)n_img * d.I));
+    NVQA_HIP(hipMemcpy(ds.Q, questions, (size_t)n_q * d.T * 4, hipMemcpyHostToDevice));
+    NVQA_HIP(hipMemcpy(ds.IP, img_pos, (size_t)n_q * 4, hipMemcpyHostToDevice));
+    NVQA_HIP(hipMemcpy(ds.ANS, answers, (size_t)n_q * 4, hipMemcpyHostToDevice));
+    NVQA_HIP(hipMemcpy(ds.F, feats, (size_t)n_img * d.I * 4, hipMemcpyHostToDevice));
+    if (lengths) {
+        NVQA_TRY(dalloc(&ds.QL, (size_t)n_q));
+        NVQA_HIP(hipMemcpy(ds.QL, lengths, (size_t)n_q * 4, hipMemcpyHostToDevice));
+    }
+    ds.n_q = n_q;
+    ds.n_img = n_img;
+    if (l2_normalize) {
+        hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I);
+        NVQA_HIP(hipGetLastError());
+        NVQA_HIP(hipStreamSynchronize(c->s));
+    }
+    return 0;
+}
+
+extern "C" int nvqa_step_indices(nvqa_ctx *c, const int64_t *qinds, const nvqa_dropout *dropout, float *loss_out)
+{
+    if (!c || !qinds) { set_error("NULL argument"); return -1; }
+    if (c->ds.n_q == 0) { set_error("nvqa_step_indices before nvqa_dataset_load"); return -1; }
+    const nvqa_dims &d = c->d;
+    for (int b = 0; b < d.B; ++b)
+        if (qinds[b] < 0 || qinds[b] >= c->ds.n_q) { set_error("qinds[%d]=%lld outside 0..%lld", b, (long long)qinds[b], (long long)c->ds.n_q - 1); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_HIP(hipMemcpyAsync(c->qinds, qinds, (size_t)d.B * 8, hipMemcpyHostToDevice, c->s));
+    {
+        ProfScope ps(c, PF_GATHER, 0, 2.0 * d.B * d.I * 4);
+        hipLaunchKernelGGL(k_gather_batch, dim3(d.B), dim3(256), 0, c->s, c->qinds, c->ds.Q, c->ds.QL, c->ds.IP,
+                           c->ds.ANS, c->ds.F, d.T, d.I, c->tok, c->len, c->lab, c->img);
+    }
+    NVQA_HIP(hipGetLastError());
+    return run_step(c, dropout, loss_out);
+}
+
+// ------------------------------------------------------------------------------------
+// data parallel: RCCL (librccl.so resolved lazily -- single-GPU users never load it)
+// ------------------------------------------------------------------------------------
+namespace {
+struct Id128 { char b[128]; }; // ncclUniqueId, passed by value
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+int load_rccl()
+{
+    if (g_rccl.h) return 0;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { set_error("cannot load librccl.so: %s", dlerror()); return -1; }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { set_error("librccl.so lacks nccl symbols"); return -1; }
+    g_rccl.h = h;
+    return 0;
+}
+} // namespace
+
+extern "C" int nvqa_comm_unique_id(void *id_out)
+{
+    if (!id_out) { set_error("NULL argument"); return -1; }
+    NVQA_TRY(load_rccl());
+    const int rc = g_rccl.GetUniqueId(id_out);
+    if (rc) { set_error("ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    return 0;
+}
+
+extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
+{
+    if (!c || !id) { set_error("NULL argument"); return -1; }
+    if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world %d/%d", rank, world); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_TRY(load_rccl());
+    Id128 idv;
+    memcpy(idv.b, id, 128);
+    void *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, world, idv, rank);
+    if (rc) { set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    c->comm = comm;
+    c->rank = rank;
+    c->world = world;
+    return 0;
+}
+
+static int allreduce_grads(nvqa_ctx *c)
+{
+    if (!c->comm || c->world == 1) return 0;
+    ProfScope ps(c, PF_ALLREDUCE, 0, 4.0 * c->lo.total);
+    // one sum over the flat gradient; the 1/world scale and the clamp run in k_rmsprop
+    const int rc = g_rccl.AllReduce(c->G, c->G, c->lo.total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->s);
+    if (rc) { set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------
+extern "C" int nvqa_profile_enable(nvqa_ctx *c, int enable)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    prof_collect(c);
+    c->prof_on = enable != 0;
+    return 0;
+}
+extern "C" int nvqa_profile_reset(nvqa_ctx *c)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    prof_collect(c);
+    for (int i = 0; i < PF_COUNT; ++i) { c->prof[i].ms = c->prof[i].flops = c->prof[i].bytes = 0; c->prof[i].launches = 0; }
+    return 0;
+}
+extern "C" int nvqa_profile_count(const nvqa_ctx *) { return PF_COUNT; }
+extern "C" const char *nvqa_profile_name(const nvqa_ctx *, int idx) { return idx >= 0 && idx < PF_COUNT ? kProfNames[idx] : ""; }
+extern "C" int nvqa_profile_get(nvqa_ctx *c, int idx, double *total_ms, int64_t *launches, double *flops, double *bytes)
+{
+    if (!c || idx < 0 || idx >= PF_COUNT) { set_error("bad profile index"); return -1; }
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    prof_collect(c);
+    if (total_ms) *total_ms = c->prof[idx].ms;
+    if (launches) *launches = c->prof[idx].launches;
+    if (flops) *flops = c->prof[idx].flops;
+    if (bytes) *bytes = c->prof[idx].bytes;
+    return 0;
+}

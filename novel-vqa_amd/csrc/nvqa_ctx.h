@@ -1,0 +1,110 @@
+// nvqa_ctx.h -- library-owned state behind the opaque nvqa_ctx of include/nvqa.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nvqa.h"
+#include "../../include/nvqa_layout.h"
+#include "epilogues.h"
+
+namespace nvqa {
+
+void set_error(const char *fmt, ...);
+
+#define NVQA_HIP(expr)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            nvqa::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                           \
+        }                                                                                        \
+    } while (0)
+
+#define NVQA_TRY(expr)                 \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != 0) return rc_;      \
+    } while (0)
+
+// Kernel groups timed by HIP events (nvqa_profile_*); one entry per launch site family.
+enum ProfId {
+    PF_ASSEMBLE = 0,
+    PF_EMB_FWD,
+    PF_GEMM_I2H,   // time-batched input projections (forward)
+    PF_LSTM_FWD,   // recurrent step: h2h GEMM + fused cell
+    PF_HEAD_PREP,
+    PF_GEMM_HEAD_FWD,
+    PF_SOFTMAX_CE,
+    PF_GEMM_HEAD_BWD,
+    PF_LSTM_BWD,   // recurrent step: dgates x W_h2h + fused cell backward
+    PF_GEMM_DGRAD, // time-batched d(input) products
+    PF_GEMM_WGRAD, // time-batched weight gradients (split-K)
+    PF_REDUCE,     // split-K slab sums
+    PF_COLSUM,     // bias gradients
+    PF_EMB_BWD,
+    PF_RMSPROP,
+    PF_ALLREDUCE,
+    PF_GATHER,
+    PF_COUNT
+};
+
+struct ProfEntry {
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Dataset {
+    int64_t n_q = 0, n_img = 0;
+    int32_t *Q = nullptr, *QL = nullptr, *IP = nullptr, *ANS = nullptr;
+    float *F = nullptr;
+};
+
+} // namespace nvqa
+
+struct nvqa_ctx {
+    nvqa_dims d;
+    nvqa_layout lo;
+    int device = 0;
+    hipStream_t s = nullptr;
+    int TS = 0; // recurrent steps: arch1 T, arch2 T+2
+
+    // parameters / gradients / RMSprop mean-square (internal layout = ABI layout with the
+    // arch1 embedding table transposed to [V][E])
+    float *P = nullptr, *G = nullptr, *M2 = nullptr;
+    bool have_grads = false;
+
+    // current batch
+    int32_t *tok = nullptr, *len = nullptr, *lab = nullptr;
+    float *img = nullptr;
+    int64_t *qinds = nullptr;
+    int32_t *sort_idx = nullptr, *sort_inv = nullptr, *nrows = nullptr, *ptok = nullptr;
+
+    // activations
+    float *X0 = nullptr, *dX0 = nullptr;       // [TS*B][E] layer-0 inputs and their gradient
+    float *Gt[NVQA_MAX_LAYERS] = {};           // [TS*B][4R] gates (fwd) / d(pre-activations) (bwd)
+    float *Hs[NVQA_MAX_LAYERS] = {};           // [(TS+1)*B][R]
+    float *Cs[NVQA_MAX_LAYERS] = {};           // [(TS+1)*B][R]
+    float *U[NVQA_MAX_LAYERS] = {};            // [TS*B][R] Dropout(h of layer below), l >= 1
+    float *dHext[NVQA_MAX_LAYERS] = {};        // [TS*B][R] dL/dh from the layer above, l < L-1
+    float *dCT = nullptr, *dHT = nullptr;      // [L][B][R] head -> final state gradients
+    float *qd = nullptr, *vd = nullptr, *qc = nullptr, *ic = nullptr, *zd = nullptr;
+    float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
+    float *dqc = nullptr, *dic = nullptr;
+    float *colpart = nullptr, *slabs = nullptr;
+    size_t slab_floats = 0;
+    int32_t *argmax = nullptr;
+    float *h_loss = nullptr; // pinned
+
+    nvqa::Dataset ds;
+
+    // data parallel
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+
+    // profiling
+    bool prof_on = false;
+    nvqa::ProfEntry prof[nvqa::PF_COUNT];
+};

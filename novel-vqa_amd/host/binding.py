@@ -1,0 +1,230 @@
+"""ctypes binding of libnvqa.so (include/nvqa.h) -- the executable twin of
+novel-vqa_amd/lua/nvqa_ffi.lua (LuaJIT is not available in the build image).
+
+There is NO fallback: if the shared library or a HIP device is missing the
+calls raise NvqaError (the product path never routes through the CPU oracle).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libnvqa.so")
+
+COMM_ID_BYTES = 128
+
+
+class NvqaError(RuntimeError):
+    pass
+
+
+class Dims(ctypes.Structure):
+    """nvqa_dims"""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")]
+
+
+class Dropout(ctypes.Structure):
+    """nvqa_dropout"""
+
+    _fields_ = [("mode", ctypes.c_int32), ("p", ctypes.c_float), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_uint64)]
+
+
+# every symbol include/nvqa.h declares: name -> (restype, argtypes)
+_vp, _i32p, _f32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+SYMBOLS = {
+    "nvqa_create": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.c_int, ctypes.POINTER(_vp)]),
+    "nvqa_destroy": (ctypes.c_int, [_vp]),
+    "nvqa_last_error": (ctypes.c_char_p, []),
+    "nvqa_sync": (ctypes.c_int, [_vp]),
+    "nvqa_param_count": (ctypes.c_size_t, [_vp]),
+    "nvqa_segments": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
+    "nvqa_init_params": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_float, ctypes.c_float]),
+    "nvqa_set_params": (ctypes.c_int, [_vp, _f32p]),
+    "nvqa_get_params": (ctypes.c_int, [_vp, _f32p]),
+    "nvqa_get_grads": (ctypes.c_int, [_vp, _f32p, ctypes.c_float]),
+    "nvqa_step": (ctypes.c_int, [_vp, _i32p, _i32p, _f32p, _i32p, ctypes.POINTER(Dropout), _f32p]),
+    "nvqa_get_loss": (ctypes.c_int, [_vp, _f32p]),
+    "nvqa_forward": (ctypes.c_int, [_vp, ctypes.c_int32, _i32p, _i32p, _f32p, _f32p, _i32p]),
+    "nvqa_rmsprop_update": (ctypes.c_int, [_vp] + [ctypes.c_float] * 5),
+    "nvqa_dataset_load": (ctypes.c_int, [_vp, ctypes.c_int64, _i32p, _i32p, _i32p, _i32p,
+                                         ctypes.c_int64, _f32p, ctypes.c_int]),
+    "nvqa_step_indices": (ctypes.c_int, [_vp, _i64p, ctypes.POINTER(Dropout), _f32p]),
+    "nvqa_comm_unique_id": (ctypes.c_int, [_vp]),
+    "nvqa_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "nvqa_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "nvqa_profile_reset": (ctypes.c_int, [_vp]),
+    "nvqa_profile_count": (ctypes.c_int, [_vp]),
+    "nvqa_profile_name": (ctypes.c_char_p, [_vp, ctypes.c_int]),
+    "nvqa_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libnvqa.so and bind every declared symbol. Raises NvqaError if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise NvqaError(f"{p} not found: build it with __graft_entry__.build() "
+                        f"(make -C novel-vqa_amd); there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f32(a):
+    return None if a is None else a.ctypes.data_as(_f32p)
+
+
+def _i32(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+class Context:
+    """Owns one nvqa_ctx (one device)."""
+
+    def __init__(self, dims, device=0):
+        self.lib = load_library()
+        self.dims = dims
+        self._h = _vp()
+        self._check(self.lib.nvqa_create(ctypes.byref(dims), device, ctypes.byref(self._h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NvqaError(f"libnvqa error {rc}: {self.lib.nvqa_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            self.lib.nvqa_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------
+    @property
+    def param_count(self):
+        return int(self.lib.nvqa_param_count(self._h))
+
+    def segments(self):
+        out = (ctypes.c_size_t * 3)()
+        self._check(self.lib.nvqa_segments(self._h, out))
+        return tuple(int(x) for x in out)
+
+    def init_params(self, seed=123, lo=-0.08, hi=0.08):
+        self._check(self.lib.nvqa_init_params(self._h, seed, lo, hi))
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, np.float32)
+        assert p.size == self.param_count
+        self._check(self.lib.nvqa_set_params(self._h, _f32(p)))
+
+    def get_params(self):
+        out = np.empty(self.param_count, np.float32)
+        self._check(self.lib.nvqa_get_params(self._h, _f32(out)))
+        return out
+
+    def get_grads(self, clamp=0.0):
+        out = np.empty(self.param_count, np.float32)
+        self._check(self.lib.nvqa_get_grads(self._h, _f32(out), clamp))
+        return out
+
+    # ---- hot path ------------------------------------------------------------
+    def step(self, tokens, lengths, img, labels, dropout=None, want_loss=True):
+        d = self.dims
+        tokens = np.ascontiguousarray(tokens, np.int32).reshape(d.B, d.T)
+        lengths = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        img = np.ascontiguousarray(img, np.float32).reshape(d.B, d.I)
+        labels = np.ascontiguousarray(labels, np.int32)
+        loss = ctypes.c_float(0)
+        dr = ctypes.byref(dropout) if dropout is not None else None
+        self._check(self.lib.nvqa_step(self._h, _i32(tokens), _i32(lengths), _f32(img), _i32(labels),
+                                       dr, ctypes.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def step_indices(self, qinds, dropout=None, want_loss=True):
+        q = np.ascontiguousarray(qinds, np.int64)
+        assert q.size == self.dims.B
+        loss = ctypes.c_float(0)
+        dr = ctypes.byref(dropout) if dropout is not None else None
+        self._check(self.lib.nvqa_step_indices(self._h, q.ctypes.data_as(_i64p), dr,
+                                               ctypes.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def get_loss(self):
+        loss = ctypes.c_float(0)
+        self._check(self.lib.nvqa_get_loss(self._h, ctypes.byref(loss)))
+        return float(loss.value)
+
+    def forward(self, tokens, lengths, img):
+        d = self.dims
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        n = tokens.shape[0]
+        lengths = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        img = np.ascontiguousarray(img, np.float32)
+        scores = np.empty((n, d.A), np.float32)
+        argmax = np.empty(n, np.int32)
+        self._check(self.lib.nvqa_forward(self._h, n, _i32(tokens), _i32(lengths), _f32(img),
+                                          _f32(scores), _i32(argmax)))
+        return scores, argmax
+
+    def rmsprop_update(self, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
+        self._check(self.lib.nvqa_rmsprop_update(self._h, lr, alpha, eps, wd, clamp))
+
+    def sync(self):
+        self._check(self.lib.nvqa_sync(self._h))
+
+    # ---- dataset ------------------------------------------------------------------
+    def dataset_load(self, questions, lengths, img_pos, answers, feats, l2_normalize=False):
+        q = np.ascontiguousarray(questions, np.int32)
+        l = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        ip = np.ascontiguousarray(img_pos, np.int32)
+        an = np.ascontiguousarray(answers, np.int32)
+        f = np.ascontiguousarray(feats, np.float32)
+        self._check(self.lib.nvqa_dataset_load(self._h, q.shape[0], _i32(q), _i32(l), _i32(ip), _i32(an),
+                                               f.shape[0], _f32(f), int(l2_normalize)))
+
+    # ---- data parallel ------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        self._check(self.lib.nvqa_comm_unique_id(ctypes.cast(buf, _vp)))
+        return buf.raw
+
+    def comm_init(self, rank, world, comm_id):
+        buf = ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self._check(self.lib.nvqa_comm_init(self._h, rank, world, ctypes.cast(buf, _vp)))
+
+    # ---- measurement ----------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.nvqa_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self.lib.nvqa_profile_reset(self._h))
+
+    def profile(self):
+        out = {}
+        for i in range(self.lib.nvqa_profile_count(self._h)):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            self._check(self.lib.nvqa_profile_get(self._h, i, ctypes.byref(ms), ctypes.byref(n),
+                                                  ctypes.byref(fl), ctypes.byref(by)))
+            out[self.lib.nvqa_profile_name(self._h, i).decode()] = {
+                "ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out

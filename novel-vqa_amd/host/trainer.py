@@ -1,0 +1,114 @@
+"""Host-side mirror of the reference's training-step interface.
+
+The reference drives training through the optim closure protocol
+(002_train_vqa_arch1/002_train_baseline.lua:272-335,394-414):
+
+    for iter = 1, max_iters do
+        optim.rmsprop(JdJ, winit, optimize, state)     -- JdJ(x) -> f, gradients
+        optimize.learningRate = optimize.learningRate * decay_factor
+    end
+
+`VQATrainer` keeps the same names and argument meaning: `JdJ()` returns
+(loss, clamped flat gradient) for one minibatch, `rmsprop()` is the fused
+device-side update, `next_batch()` mirrors dataset:next_batch() (:195-222),
+`validate()`/`predict()` mirror the eval-mode forward (:337-381,
+004_eval_model.lua:202-233).  Same file serves arch1 and arch2.
+"""
+import numpy as np
+
+from . import binding
+
+DECAY_FACTOR = 0.99997592083  # 002_train_baseline.lua:78
+
+
+class VQATrainer:
+    def __init__(self, dims, device=0, learning_rate=3e-4, alpha=0.99, epsilon=1e-8,
+                 weight_decay=None, clamp=10.0, seed=123, dropout_p=0.5, dropout=True):
+        self.dims = dims
+        self.ctx = binding.Context(dims, device)
+        self.learningRate = learning_rate
+        self.alpha, self.epsilon, self.clamp = alpha, epsilon, clamp
+        # arch2 baseline sets optimize.weightDecay = 1e-4 (003_.../002_train_baseline.lua:197)
+        self.weightDecay = (1e-4 if dims.arch == 2 else 0.0) if weight_decay is None else weight_decay
+        self.seed = seed
+        self.iter = 0
+        self.dropout_p = dropout_p
+        self.dropout_on = dropout
+        self.running_avg = None
+        self.rng = np.random.default_rng(seed)
+        self.n_questions = 0
+
+    # -- parameters (join_vector({encoder_w_q, embedding_w_q, multimodal_w})) ---------------
+    def init_params(self, lo=-0.08, hi=0.08):
+        self.ctx.init_params(self.seed, lo, hi)
+
+    def set_params(self, x):
+        self.ctx.set_params(x)
+
+    def get_params(self):
+        return self.ctx.get_params()
+
+    def _dropout(self):
+        return binding.Dropout(1 if self.dropout_on else 0, self.dropout_p, self.seed, self.iter)
+
+    # -- dataset:next_batch() -------------------------------------------------------------------
+    def load_dataset(self, questions, lengths, img_pos, answers, feats, img_norm=True):
+        """dataset[...] tensors (:93-121); right_align must already be applied for arch1."""
+        self.ctx.dataset_load(questions, lengths, img_pos, answers, feats, l2_normalize=img_norm)
+        self.n_questions = int(np.asarray(questions).shape[0])
+
+    def next_batch(self):
+        """qinds[i] = torch.random(nqs): sampling with replacement on the host (:202-205)."""
+        return self.rng.integers(0, self.n_questions, self.dims.B, dtype=np.int64)
+
+    # -- JdJ -----------------------------------------------------------------------------------------
+    def JdJ(self, batch=None, want_grads=True):
+        """One forward+backward. batch = (tokens, lengths, img, labels) or None to draw
+        from the loaded dataset.  Returns (f, gradients) like the reference closure."""
+        if batch is None:
+            f = self.ctx.step_indices(self.next_batch(), self._dropout())
+        else:
+            tokens, lengths, img, labels = batch
+            f = self.ctx.step(tokens, lengths, img, labels, self._dropout())
+        self.running_avg = f if self.running_avg is None else self.running_avg * 0.95 + f * 0.05
+        return f, (self.ctx.get_grads(self.clamp) if want_grads else None)
+
+    def rmsprop(self):
+        """optim.rmsprop's update for the gradient left on the device by JdJ, then the
+        per-iteration LR decay (:408-410)."""
+        self.ctx.rmsprop_update(self.learningRate, self.alpha, self.epsilon, self.weightDecay, self.clamp)
+        self.learningRate *= DECAY_FACTOR
+        self.iter += 1
+
+    def train_iteration(self, batch=None):
+        f, _ = self.JdJ(batch, want_grads=False)
+        self.rmsprop()
+        return f
+
+    # -- evaluation ------------------------------------------------------------------------------------
+    def predict(self, tokens, lengths, img):
+        """Eval-mode forward: (scores [n, A], argmax [n] 1-based), 004_eval_model.lua:202-233."""
+        tokens = np.asarray(tokens)
+        B = self.dims.B
+        scores, preds = [], []
+        for s in range(0, tokens.shape[0], B):
+            sc, am = self.ctx.forward(tokens[s:s + B], None if lengths is None else lengths[s:s + B],
+                                      img[s:s + B])
+            scores.append(sc)
+            preds.append(am)
+        return np.concatenate(scores), np.concatenate(preds)
+
+    def close(self):
+        self.ctx.close()
+
+
+def multiple_choice_argmax(scores, mc_ans):
+    """Masked argmax over the non-zero candidate ids (004_eval_model.lua:259-271).
+    scores [n, A]; mc_ans [n, 18] 1-based answer ids, 0 = empty slot. Returns 1-based ids."""
+    scores = np.asarray(scores, np.float64)
+    mc_ans = np.asarray(mc_ans)
+    out = np.zeros(scores.shape[0], np.int64)
+    for i in range(scores.shape[0]):
+        cand = mc_ans[i][mc_ans[i] != 0]
+        out[i] = cand[np.argmax(scores[i, cand - 1])]  # first maximal candidate, like torch.max
+    return out
