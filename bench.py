@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- QA-pairs/sec of the arch1 VQA training step on N MI355X (BASELINE.json metric).
+
+One "step" = dataset:next_batch() gather on the device + forward + backward + (N>1: RCCL
+all-reduce of the flat gradient) + clamp + RMSprop, B = 512 QA pairs per GPU, on synthetic data
+that is resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as ge  # noqa: E402
+
+# BASELINE.json configs[1]: arch1 baseline, VGG fc7 feats, 1000-way answers, batch 512 fp32
+WORKLOAD = dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000)
+N_QUESTIONS, N_IMAGES = 65536, 8192
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def flops_per_qa(w):
+    """Algorithmic FLOPs per QA pair per training step (SURVEY.md 8d / BASELINE.md section 4):
+    3 x forward (fwd + dgrad + wgrad) minus the never-computed gradient to the image input;
+    the embedding is a gather (0 FLOP)."""
+    E, R, L, I, C, A, T = w["E"], w["R"], w["L"], w["I"], w["C"], w["A"], w["T"]
+    per_tok = 0
+    for l in range(L):
+        inn = E if l == 0 else R
+        per_tok += 2 * 4 * R * (inn + R)
+    head = 2 * (C * 2 * R * L + C * I + A * C)
+    fwd = T * per_tok + head
+    # no d/d(image) and no d/d(embedding output beyond the table): drop dX of the image Linear
+    return 3 * fwd - 2 * C * I, fwd
+
+
+def synth_dataset(w, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(1, w["V"] + 1, (N_QUESTIONS, w["T"]), dtype=np.int32)  # all lengths = T
+    lens = np.full(N_QUESTIONS, w["T"], np.int32)
+    img_pos = rng.integers(1, N_IMAGES + 1, N_QUESTIONS, dtype=np.int32)
+    ans = rng.integers(1, w["A"] + 1, N_QUESTIONS, dtype=np.int32)
+    feats = np.abs(rng.standard_normal((N_IMAGES, w["I"]), dtype=np.float32))  # normalised on device
+    return q, lens, img_pos, ans, feats
+
+
+def cpu_baseline(w):
+    """The oracle (CPU restatement, NOT Torch7) timed on this host: one step of the same batch."""
+    from oracle import oracle as orc
+    d = orc.make_dims(**w)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d)
+    o = orc.Oracle(np.float32)
+    small = orc.make_dims(**{**w, "B": 16})
+    ts, ls, ims, las = orc.synth_batch(small)
+    o.step(small, params, ts, ls, ims, las, orc.Dropout(1, 0.5, 123, 0))  # warm up threads/pages
+    t0 = time.perf_counter()
+    o.step(d, params, tok, lens, img, lab, orc.Dropout(1, 0.5, 123, 0))
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0))
+    return {"value": round(w["B"] / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 forward+backward of the same B={w['B']} batch (no optimiser step), "
+                      f"OpenMP C restatement oracle/nvqa_oracle.c, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # gloo carries only the rendezvous, the barrier and the max-over-ranks; the gradient
+        # all-reduce is RCCL inside libnvqa
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    pkg = ge.load_package()
+    w = WORKLOAD
+    dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
+    tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123)
+    tr.init_params()  # same on every rank (counter-based)
+    tr.rng = np.random.default_rng(123 + 1000 * rank)  # each rank draws its own sample ids
+    tr.load_dataset(*synth_dataset(w, 123), img_norm=True)
+    if world > 1:
+        ids = [tr.ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        tr.ctx.comm_init(rank, world, ids[0])
+
+    def barrier():
+        tr.ctx.sync()
+        torch.cuda.synchronize(local_rank)
+        if dist:
+            dist.barrier()
+
+    def one_step():
+        tr.ctx.step_indices(tr.next_batch(), tr._dropout(), want_loss=False)
+        tr.rmsprop()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss = tr.ctx.get_loss()
+
+    fl_qa, _ = flops_per_qa(w)
+    value = w["B"] * world * args.steps / dt
+    out = {
+        "metric": "QA-pairs/sec training step (batch 512, seq 26)", "value": round(value, 1),
+        "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "arch1 002_train_baseline: V=14773 E=200 R=512 L=2 I=4096 C=1024 A=1000, "
+                               "all lengths 26, dropout 0.5 on, HBM-resident dataset, RMSprop",
+                   "global_batch": w["B"] * world, "seq_len": w["T"], "parallelism": f"dp{world}"},
+        "flop_per_qa": fl_qa,
+        "step_mfma_frac": round(value * fl_qa / (world * FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+        "final_loss": round(loss, 5),
+    }
+
+    if not args.no_roofline:
+        # per-kernel HIP-event timing on the library's stream, in a separate (untimed) pass;
+        # every rank runs the steps (the all-reduce needs them), rank 0 records
+        nprof = 3
+        if rank == 0:
+            tr.ctx.profile_enable(True)
+            tr.ctx.profile_reset()
+        for _ in range(nprof):
+            one_step()
+        tr.ctx.sync()
+        if rank == 0:
+            prof = tr.ctx.profile()
+            tr.ctx.profile_enable(False)
+            gemm = {k: v for k, v in prof.items() if v["flops"] > 0 and v["launches"] > 0}
+            dom = max(gemm, key=lambda k: gemm[k]["ms"])
+            pv = gemm[dom]
+            avg_ms = pv["ms"] / pv["launches"]
+            ach = pv["flops"] / pv["launches"] / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(avg_ms, 5),
+                               "launches_per_step": pv["launches"] // nprof}
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in prof.items()
+                                         if v["launches"]}
+    if dist:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    tr.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

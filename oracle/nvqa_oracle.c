@@ -528,3 +528,27 @@ void oracle_onehot_linear(int n, int V, int E, const int32_t *words /*1-based*/,
     lin_fwd(n, E, V, oh, We, be, out);
     free(oh);
 }
+
+/* Offsets of include/nvqa_layout.h, exported so the tests can check the Python mirror
+ * (oracle.layout) and the library against the one C definition. out[] order:
+ * total, seg0, seg1, seg2, then per layer (w_i2h, b_i2h, w_h2h, b_h2h), then
+ * w_e, b_e, w_q, b_q, w_v, b_v, w_o, b_o, w_p, b_p, w_lk.  Returns the count written. */
+int oracle_layout(const nvqa_dims *d, uint64_t *out)
+{
+    nvqa_layout lo;
+    if (nvqa_layout_init(d, &lo)) return -1;
+    int n = 0;
+    out[n++] = lo.total; out[n++] = lo.seg[0]; out[n++] = lo.seg[1]; out[n++] = lo.seg[2];
+    for (int l = 0; l < d->L; ++l) {
+        out[n++] = lo.w_i2h[l]; out[n++] = lo.b_i2h[l]; out[n++] = lo.w_h2h[l]; out[n++] = lo.b_h2h[l];
+    }
+    out[n++] = lo.w_e; out[n++] = lo.b_e; out[n++] = lo.w_q; out[n++] = lo.b_q; out[n++] = lo.w_v;
+    out[n++] = lo.b_v; out[n++] = lo.w_o; out[n++] = lo.b_o; out[n++] = lo.w_p; out[n++] = lo.b_p;
+    out[n++] = lo.w_lk;
+    return n;
+}
+
+uint32_t oracle_hash32(uint64_t seed, uint64_t step, uint32_t site, uint64_t idx)
+{
+    return nvqa_hash32(seed, step, site, idx);
+}

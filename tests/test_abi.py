@@ -1,0 +1,53 @@
+"""The C-ABI library: every function include/nvqa.h declares is exported and bound, and the
+product path fails loudly when no HIP device exists (no CPU fallback).  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "nvqa.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nvqa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.binding.load_library()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nvqa.h but not exported"
+    assert sorted(pkg.binding.SYMBOLS) == names, "binding.SYMBOLS must mirror include/nvqa.h"
+
+
+def test_struct_sizes_match_header(pkg):
+    assert ctypes.sizeof(pkg.binding.Dims) == 40
+    assert ctypes.sizeof(pkg.binding.Dropout) == 24
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path):
+    with pytest.raises(pkg.binding.NvqaError):
+        pkg.binding.load_library(str(tmp_path / "libnvqa.so"))
+
+
+def test_no_device_is_an_error_not_a_fallback(pkg, orc):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    d = orc.make_dims(arch=1, B=4, T=5, V=11, E=8, R=8, L=2, I=12, C=12, A=8)
+    with pytest.raises(pkg.binding.NvqaError) as e:
+        pkg.binding.Context(pkg.binding.Dims(*[getattr(d, n) for n, _ in d._fields_]), 0)
+    assert "no HIP device" in str(e.value) or "failed" in str(e.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "novel-vqa_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".lua")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower().replace("cpu oracle", "").replace("the oracle", ""), \
+                    f"{f} references the oracle"
