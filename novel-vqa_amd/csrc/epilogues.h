@@ -32,6 +32,19 @@ struct EpiStore {
     }
 };
 
+// C[m][n] += v : time-chunked weight gradients accumulate in launch order on one stream
+// (nn.Linear accGradParameters summed over the LSTM clones, 002_train_baseline.lua:323-326)
+struct EpiAccum {
+    float *C;
+    int ldc;
+    int first; // 1: overwrite (first chunk), 0: accumulate
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        float *p = C + (size_t)m * ldc + n;
+        *p = first ? v : *p + v;
+    }
+};
+
 // nn.Linear bias add (two biases: b_i2h + b_h2h of misc/LSTM.lua:41-43 folded into the
 // time-batched i2h product)
 struct EpiBias2 {
@@ -124,23 +137,43 @@ struct EpiLstmFwd {
     const float *c_prev; // [B][R]
     float *c, *h;        // [B][R]
     float *u_next;       // optional [B][R]: Dropout(h) = input of the next layer at this step
+    const float *bias1, *bias2; // non-NULL: a[] already holds both products (two-segment K), add the
+                                // biases instead of reading a precomputed input projection from gx
     const int *nrows, *sort_idx;
     int R, B, T, t, lnext_m1; // lnext_m1 = (l+1)-1 = l for the dropout index of layer l+1
     Drop dr;
-    __device__ __forceinline__ void operator()(int m, int u, const float (&a)[4]) const
+    // epilogue inputs that do not depend on the product: fetched BEFORE the K loop so that their
+    // L2/HBM latency hides under it (the step kernels are latency-critical)
+    struct Pre { float p0, p1, p2, p3, cp; int nr; };
+    __device__ __forceinline__ Pre preload(int m, int u) const
+    {
+        const size_t gi = (size_t)m * 4 * R + u;
+        Pre q;
+        if (bias1) {
+            q.p0 = bias1[u] + bias2[u]; q.p1 = bias1[R + u] + bias2[R + u];
+            q.p2 = bias1[2 * R + u] + bias2[2 * R + u]; q.p3 = bias1[3 * R + u] + bias2[3 * R + u];
+        } else {
+            q.p0 = gx[gi]; q.p1 = gx[gi + R]; q.p2 = gx[gi + 2 * R]; q.p3 = gx[gi + 3 * R];
+        }
+        q.cp = c_prev[(size_t)m * R + u];
+        q.nr = *nrows;
+        return q;
+    }
+    __device__ __forceinline__ void operator()(int m, int u, const float (&a)[4]) const { (*this)(m, u, a, preload(m, u)); }
+    __device__ __forceinline__ void operator()(int m, int u, const float (&a)[4], const Pre &q) const
     {
         const size_t gi = (size_t)m * 4 * R + u, si = (size_t)m * R + u;
-        if (m >= *nrows) {
+        if (m >= q.nr) {
             gx[gi] = 0.f; gx[gi + R] = 0.f; gx[gi + 2 * R] = 0.f; gx[gi + 3 * R] = 0.f;
             c[si] = 0.f; h[si] = 0.f;
             if (u_next) u_next[si] = 0.f;
             return;
         }
-        const float ig = sigmoidf_(a[0] + gx[gi]);
-        const float fg = sigmoidf_(a[1] + gx[gi + R]);
-        const float og = sigmoidf_(a[2] + gx[gi + 2 * R]);
-        const float gg = tanhf_(a[3] + gx[gi + 3 * R]);
-        const float cn = fg * c_prev[si] + ig * gg;
+        const float ig = sigmoidf_(a[0] + q.p0);
+        const float fg = sigmoidf_(a[1] + q.p1);
+        const float og = sigmoidf_(a[2] + q.p2);
+        const float gg = tanhf_(a[3] + q.p3);
+        const float cn = fg * q.cp + ig * gg;
         const float hn = og * tanhf_(cn);
         gx[gi] = ig; gx[gi + R] = fg; gx[gi + 2 * R] = og; gx[gi + 3 * R] = gg;
         c[si] = cn; h[si] = hn;
@@ -161,26 +194,49 @@ struct EpiLstmBwd {
     const float *dh_ext, *dh_ext2; // optional extra dL/dh_s terms (upper layer, head)
     const int *nrows;
     int R;
-    __device__ __forceinline__ void operator()(int, int m, int u, float v) const
+    // two-accumulator form (SEG == 2): v2 = (dG^{l+1}_s W_i2h^{l+1})[m][u], the gradient reaching
+    // h^l_s through the inter-layer Dropout of misc/LSTM.lua:37
+    const int *sort_idx;
+    int B, T, s, lm1;
+    Drop dr;
+    int has_upper; // 0 for the top layer (v2 is identically zero)
+    struct Pre { float ig, fg, og, gg, c, cp, dc, dhx, dscale; int nr; };
+    __device__ __forceinline__ Pre preload(int m, int u) const
     {
         const size_t gi = (size_t)m * 4 * R + u, si = (size_t)m * R + u;
-        if (m >= *nrows) { // gradient rows of not-yet-started questions are dropped (RNNUtils.lua:192-196)
+        Pre q;
+        q.ig = gates[gi]; q.fg = gates[gi + R]; q.og = gates[gi + 2 * R]; q.gg = gates[gi + 3 * R];
+        q.c = c[si]; q.cp = c_prev[si]; q.dc = dc[si];
+        q.dhx = (dh_ext ? dh_ext[si] : 0.f) + (dh_ext2 ? dh_ext2[si] : 0.f);
+        q.dscale = has_upper ? dr.scale(NVQA_SITE_LSTM, ((((uint64_t)lm1) * B + sort_idx[m]) * T + s) * R + u) : 0.f;
+        q.nr = *nrows;
+        return q;
+    }
+    __device__ __forceinline__ void operator()(int z, int m, int u, float v, float v2) const { (*this)(z, m, u, v, v2, preload(m, u)); }
+    __device__ __forceinline__ void operator()(int z, int m, int u, float v) const { (*this)(z, m, u, v, 0.f, preload(m, u)); }
+    __device__ __forceinline__ void operator()(int, int m, int u, float v, float v2, const Pre &q) const
+    {
+        const size_t gi = (size_t)m * 4 * R + u, si = (size_t)m * R + u;
+        if (m >= q.nr) { // gradient rows of not-yet-started questions are dropped (RNNUtils.lua:192-196)
             gates[gi] = 0.f; gates[gi + R] = 0.f; gates[gi + 2 * R] = 0.f; gates[gi + 3 * R] = 0.f;
             dc[si] = 0.f;
             return;
         }
-        float dh = v;
-        if (dh_ext) dh += dh_ext[si];
-        if (dh_ext2) dh += dh_ext2[si];
-        const float ig = gates[gi], fg = gates[gi + R], og = gates[gi + 2 * R], gg = gates[gi + 3 * R];
-        const float tc = tanhf_(c[si]);
-        const float dcv = dc[si] + dh * og * (1.0f - tc * tc);
+        const float dh = v + q.dscale * v2 + q.dhx;
+        const float ig = q.ig, fg = q.fg, og = q.og, gg = q.gg;
+        const float tc = tanhf_(q.c);
+        const float dcv = q.dc + dh * og * (1.0f - tc * tc);
         gates[gi] = dcv * gg * ig * (1.0f - ig);
-        gates[gi + R] = dcv * c_prev[si] * fg * (1.0f - fg);
+        gates[gi + R] = dcv * q.cp * fg * (1.0f - fg);
         gates[gi + 2 * R] = dh * tc * og * (1.0f - og);
         gates[gi + 3 * R] = dcv * ig * (1.0f - gg * gg);
         dc[si] = dcv * fg;
     }
 };
+
+// epilogues with a preload() step (see EpiLstmFwd::Pre)
+template <class E> struct EpiTraits { static constexpr bool prefetch = false; struct Pre {}; };
+template <> struct EpiTraits<EpiLstmFwd> { static constexpr bool prefetch = true; typedef EpiLstmFwd::Pre Pre; };
+template <> struct EpiTraits<EpiLstmBwd> { static constexpr bool prefetch = true; typedef EpiLstmBwd::Pre Pre; };
 
 } // namespace nvqa

@@ -2,7 +2,7 @@
 // (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact f32 fma chains at the
 // f32 vector rate, MI355X_MICROARCH.md "Matrix cores").  Every dense product of the
 // VQA step runs through this template; what differs per call site is the operand
-// layout, the tile shape and the fused epilogue.
+// layout, the tile shape, the pipeline depth and the fused epilogue.
 //
 // Replaces the cuBLAS sgemm calls behind nn.Linear forward / updateGradInput /
 // accGradParameters (reference: 002_train_vqa_arch1/misc/LSTM.lua:41-42,
@@ -19,6 +19,13 @@
 // consecutive floats per k: conflict-free ds_read_b32.  K-contiguous sources are transposed
 // on the LDS write (pad chosen so the 4 scalar writes of a float4 hit distinct banks).
 //
+// Pipeline (PF = 2): two LDS buffers and two register tile sets; the global loads of tiles
+// t+1 and t+2 are in flight while tile t is multiplied, one barrier per tile.  The small
+// per-step LSTM products are latency-bound (one workgroup per CU, operands in L2), so what
+// matters is bytes in flight per CU, not MFMA scheduling.  WK > 1 splits each K-tile over
+// WK wave groups (more waves per SIMD to hide LDS/MFMA latency) and sums the partial
+// accumulators through LDS in a fixed order before the epilogue.
+//
 // GATES mode (fused LSTM cell): N indexes hidden units; the block's B tile holds the
 // rows {g*R + u} of the [4R][K] weight for its units u and all 4 gates g, and each lane
 // ends up with the 4 gate pre-activations of one (row, unit) in its own registers, so
@@ -28,6 +35,7 @@
 #include <stdint.h>
 
 namespace nvqa {
+template <class E> struct EpiTraits; // epilogues.h
 
 enum { A_KC = 0, A_MC = 1 };
 enum { B_KC = 0, B_NC = 1 };
@@ -43,6 +51,12 @@ struct GemmArgs {
     int kslice;        // K range per blockIdx.z (multiple of BK); >= K for no split
     int R;             // GATES: gate stride inside the [4R][K] weight
     const int *mlimit; // optional device int: rows >= *mlimit are inactive (MFMA work skipped)
+    // optional second K segment (SEG > 0): C += A2 * B2, same layouts as A / B.
+    // SEG == 1 adds into the same accumulator ([x_t | h_{t-1}] x [W_i2h | W_h2h]^T of one LSTM
+    // step); SEG == 2 keeps a second accumulator that the epilogue receives separately.
+    const float *A2;
+    const float *B2;
+    int lda2, ldb2, K2;
 };
 
 template <int MF> struct AccT;
@@ -62,39 +76,73 @@ __device__ __forceinline__ f32x4 mfma<16>(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Tile configuration
+// DBG (ablation builds of tools/kbench only): 1 = no global loads, 2 = no MFMA loop, 4 = no epilogue
+template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0> struct Cfg {
+    static constexpr int MF = MF_, BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_, PF = PF_;
+    static constexpr int DBG = DBG_;
+};
+
 // Epilogue concept:
-//   plain : void operator()(int z, int m, int n, float v) const
-//   GATES : void operator()(int m, int unit, const float (&a)[4]) const
+//   plain         : void operator()(int z, int m, int n, float v) const
+//   plain, SEG==2 : void operator()(int z, int m, int n, float v, float v2) const
+//   GATES         : void operator()(int m, int unit, const float (&a)[4]) const
 // Called only for m < M, n < N.
 
-template <int MF, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GATES, class Epi>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g, Epi epi)
+// swizzle of the 16-byte chunk index inside a K-contiguous LDS row (conflict-free ds_read_b128
+// for the lane groups of MI355X_MICROARCH.md "LDS"): rows of 256 B or more XOR the low 4 chunk
+// bits with the row, 128-B rows XOR 3 bits with row/2.
+template <int BK> __device__ __forceinline__ int swz_chunk(int row, int chunk)
 {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int KI = 64 / MF;       // k per MFMA
+    if constexpr (BK >= 64) return chunk ^ (row & 15);
+    else return chunk ^ ((row >> 1) & 7);
+}
+
+template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi, const int bx, const int by,
+                                              const int bz)
+{
+    constexpr int MF = C::MF, BM = C::BM, BN = C::BN, BK = C::BK, WM = C::WM, WN = C::WN, WK = C::WK,
+                  PF = C::PF;
+    constexpr int NT = 64 * WM * WN * WK;
+    constexpr int KI = 64 / MF;        // k per MFMA (lane groups h = 0..KI-1)
+    constexpr int QK = 4 * KI;         // k per "q step": 4 MFMAs, k(q,w,h) = QK*q + 4*h + w
+    constexpr int NQ = BK / QK;        // q steps per K-tile
+    constexpr int QPW = NQ / WK;       // q steps per wave group
     constexpr int NREG = MF * MF / 64; // accumulator registers per MFMA tile
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int NTM = TM / MF, NTN = TN / MF;
     constexpr int BU = BN / 4; // GATES: units per block
     static_assert(TM % MF == 0 && TN % MF == 0, "wave tile must be a multiple of the MFMA tile");
     static_assert(!GATES || (NTN == 4 && BMODE == B_KC), "GATES: 4 gate sub-tiles per wave, weight [4R][K]");
-    static_assert(BK % 4 == 0 && BK % KI == 0, "BK");
-    // pad: transposing (K-contiguous) writes want LD % 8 == 1; float4 row writes want LD % 4 == 0
-    constexpr int LDA = AMODE == A_KC ? BM + 1 : BM + 4;
-    constexpr int LDB = BMODE == B_KC ? BN + 1 : BN + 4;
+    static_assert(BK == 32 || BK == 64 || BK == 128, "BK");
+    static_assert(NQ % WK == 0 && NREG % WK == 0, "WK must divide the q steps and the accumulator registers");
+    static_assert(PF == 1 || PF == 2, "PF");
+    static_assert(SEG != 2 || !GATES, "SEG 2 is for the plain epilogue");
+    // K-contiguous operands: LDS image [rows][BK], chunk-swizzled, read with ds_read_b128.
+    // M/N-contiguous operands: LDS image [BK][rows + 4], read with ds_read_b32 (the 4 floats of a
+    // q step sit 4 rows apart for the KI lane groups: (4*LD) % 32 == 16 keeps MF=16 conflict-free).
+    constexpr int LDA = AMODE == A_KC ? BK : BM + 4;
+    constexpr int LDB = BMODE == B_KC ? BK : BN + 4;
+    constexpr int A_FL = AMODE == A_KC ? BM * BK : BK * LDA;
+    constexpr int B_FL = BMODE == B_KC ? BN * BK : BK * LDB;
     constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
     constexpr int NA = (A_F4 + NT - 1) / NT, NB = (B_F4 + NT - 1) / NT;
+    constexpr int BUF = A_FL + B_FL; // floats per LDS buffer (A image then B image)
+    constexpr int ACCN = NTM * NTN * NREG;
+    constexpr int RED = WK > 1 ? WK * WM * WN * ACCN * 64 : 0;
+    constexpr int SMEM = (PF * BUF > RED ? PF * BUF : RED);
 
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN), wrem = wave % (WM * WN);
+    const int wm = wrem / WN, wn = wrem % WN;
     const int li = lane % MF, lh = lane / MF;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = GATES ? blockIdx.x * BU : blockIdx.x * BN; // GATES: first unit
-    const int z = blockIdx.z;
+    const int m0 = by * BM;
+    const int n0 = GATES ? bx * BU : bx * BN; // GATES: first unit
+    const int z = bz;
     const int kbeg = z * g.kslice;
     const int kend = min(g.K, kbeg + g.kslice);
     const int mlim = g.mlimit ? min(g.M, *g.mlimit) : g.M;
@@ -107,23 +155,71 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g, Epi 
         for (int b = 0; b < NTN; ++b)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) acc[a][b][r] = 0.0f;
+    typename AccT<MF>::type acc2[SEG == 2 ? NTM : 1][SEG == 2 ? NTN : 1];
+    if constexpr (SEG == 2) {
+#pragma unroll
+        for (int a = 0; a < NTM; ++a)
+#pragma unroll
+            for (int b = 0; b < NTN; ++b)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) acc2[a][b][r] = 0.0f;
+    }
 
-    float4 ra[NA], rb[NB];
+    // epilogue inputs that do not depend on the accumulators are requested now (EpiTraits::prefetch)
+    constexpr bool PRE = EpiTraits<Epi>::prefetch;
+    typename EpiTraits<Epi>::Pre pre[PRE ? NTM : 1][PRE && !GATES ? NTN : 1][PRE ? NREG : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                if (WK > 1 && r % WK != wk) continue;
+                const int m = m0 + wm * TM + ta * MF + 8 * (r >> 2) + 4 * lh + (r & 3);
+                if (m >= g.M) continue;
+                if constexpr (GATES) {
+                    const int u = n0 + wn * MF + li;
+                    if (u < g.N) pre[ta][0][r] = epi.preload(m, u);
+                } else {
+#pragma unroll
+                    for (int tb = 0; tb < NTN; ++tb) {
+                        const int n = n0 + wn * TN + tb * MF + li;
+                        if (n < g.N) pre[ta][tb][r] = epi.preload(m, n);
+                    }
+                }
+            }
+    }
 
-    auto load_tiles = [&](int k0) {
+    // tile index -> (segment, k range)
+    const int nk1 = active && kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    const int nk2 = SEG > 0 && active ? (g.K2 + BK - 1) / BK : 0;
+    const int nk = nk1 + nk2;
+
+    auto load_tiles = [&](int kt, float4(&ra)[NA], float4(&rb)[NB]) {
+        const bool s2 = SEG > 0 && kt >= nk1;
+        const float *gA = s2 ? g.A2 : g.A, *gB = s2 ? g.B2 : g.B;
+        const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
+        const int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
+        const int kend = s2 ? g.K2 : min(g.K, kbeg + g.kslice);
+        if constexpr (C::DBG & 1) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) ra[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) rb[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int f = tid + j * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < A_F4) {
+            if (A_F4 % NT == 0 || f < A_F4) {
                 if (AMODE == A_KC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
                     const int m = m0 + row, k = k0 + 4 * kq;
-                    if (m < mlim && k < kend) v = *reinterpret_cast<const float4 *>(g.A + (size_t)m * g.lda + k);
+                    if (m < mlim && k < kend) v = *reinterpret_cast<const float4 *>(gA + (size_t)m * glda + k);
                 } else {
                     const int kr = f / (BM / 4), mq = f % (BM / 4);
                     const int k = k0 + kr, m = m0 + 4 * mq;
-                    if (k < kend && m < g.M) v = *reinterpret_cast<const float4 *>(g.A + (size_t)k * g.lda + m);
+                    if (k < kend && m < g.M) v = *reinterpret_cast<const float4 *>(gA + (size_t)k * glda + m);
                 }
             }
             ra[j] = v;
@@ -132,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g, Epi 
         for (int j = 0; j < NB; ++j) {
             const int f = tid + j * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < B_F4) {
+            if (B_F4 % NT == 0 || f < B_F4) {
                 if (BMODE == B_KC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
                     const int k = k0 + 4 * kq;
@@ -146,27 +242,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g, Epi 
                         n = n0 + row;
                         ok = n < g.N;
                     }
-                    if (ok && k < kend) v = *reinterpret_cast<const float4 *>(g.B + (size_t)n * g.ldb + k);
+                    if (ok && k < kend) v = *reinterpret_cast<const float4 *>(gB + (size_t)n * gldb + k);
                 } else {
                     const int kr = f / (BN / 4), nq = f % (BN / 4);
                     const int k = k0 + kr, n = n0 + 4 * nq;
-                    if (k < kend && n < g.N) v = *reinterpret_cast<const float4 *>(g.B + (size_t)k * g.ldb + n);
+                    if (k < kend && n < g.N) v = *reinterpret_cast<const float4 *>(gB + (size_t)k * gldb + n);
                 }
             }
             rb[j] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf, const float4(&ra)[NA], const float4(&rb)[NB]) {
+        float *As = smem + buf * BUF, *Bs = As + A_FL;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int f = tid + j * NT;
-            if (f < A_F4) {
+            if (A_F4 % NT == 0 || f < A_F4) {
                 if (AMODE == A_KC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
-                    As[(4 * kq + 0) * LDA + row] = ra[j].x;
-                    As[(4 * kq + 1) * LDA + row] = ra[j].y;
-                    As[(4 * kq + 2) * LDA + row] = ra[j].z;
-                    As[(4 * kq + 3) * LDA + row] = ra[j].w;
+                    *reinterpret_cast<float4 *>(&As[row * BK + 4 * swz_chunk<BK>(row, kq)]) = ra[j];
                 } else {
                     const int kr = f / (BM / 4), mq = f % (BM / 4);
                     *reinterpret_cast<float4 *>(&As[kr * LDA + 4 * mq]) = ra[j];
@@ -176,13 +270,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g, Epi 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int f = tid + j * NT;
-            if (f < B_F4) {
+            if (B_F4 % NT == 0 || f < B_F4) {
                 if (BMODE == B_KC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
-                    Bs[(4 * kq + 0) * LDB + row] = rb[j].x;
-                    Bs[(4 * kq + 1) * LDB + row] = rb[j].y;
-                    Bs[(4 * kq + 2) * LDB + row] = rb[j].z;
-                    Bs[(4 * kq + 3) * LDB + row] = rb[j].w;
+                    *reinterpret_cast<float4 *>(&Bs[row * BK + 4 * swz_chunk<BK>(row, kq)]) = rb[j];
                 } else {
                     const int kr = f / (BN / 4), nq = f % (BN / 4);
                     *reinterpret_cast<float4 *>(&Bs[kr * LDB + 4 * nq]) = rb[j];
@@ -190,70 +281,199 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g, Epi 
             }
         }
     };
-
-    if (active && kbeg < kend) {
-        load_tiles(kbeg);
-        store_tiles();
-        __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            const bool more = k0 + BK < kend;
-            if (more) load_tiles(k0 + BK);
+    auto compute = [&](int buf, typename AccT<MF>::type(&acc)[NTM][NTN]) {
+        if constexpr (C::DBG & 2) return;
+        const float *As = smem + buf * BUF, *Bs = As + A_FL;
 #pragma unroll
-            for (int kk = 0; kk < BK / KI; ++kk) {
-                float a[NTM], b[NTN];
-                const int krow = kk * KI + lh;
+        for (int qq = 0; qq < QPW; ++qq) {
+            const int q = wk * QPW + qq;
+            float4 a[NTM], b[NTN];
 #pragma unroll
-                for (int t = 0; t < NTM; ++t) a[t] = As[krow * LDA + wm * TM + t * MF + li];
-#pragma unroll
-                for (int t = 0; t < NTN; ++t) {
-                    const int nl = GATES ? t * BU + wn * MF + li : wn * TN + t * MF + li;
-                    b[t] = Bs[krow * LDB + nl];
+            for (int t = 0; t < NTM; ++t) {
+                const int row = wm * TM + t * MF + li;
+                if constexpr (AMODE == A_KC) {
+                    a[t] = *reinterpret_cast<const float4 *>(&As[row * BK + 4 * swz_chunk<BK>(row, KI * q + lh)]);
+                } else {
+                    const float *p = &As[(QK * q + 4 * lh) * LDA + row];
+                    a[t] = make_float4(p[0], p[LDA], p[2 * LDA], p[3 * LDA]);
                 }
+            }
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) {
+                const int col = GATES ? t * BU + wn * MF + li : wn * TN + t * MF + li;
+                if constexpr (BMODE == B_KC) {
+                    b[t] = *reinterpret_cast<const float4 *>(&Bs[col * BK + 4 * swz_chunk<BK>(col, KI * q + lh)]);
+                } else {
+                    const float *p = &Bs[(QK * q + 4 * lh) * LDB + col];
+                    b[t] = make_float4(p[0], p[LDB], p[2 * LDB], p[3 * LDB]);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
 #pragma unroll
                 for (int ta = 0; ta < NTM; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < NTN; ++tb) acc[ta][tb] = mfma<MF>(a[ta], b[tb], acc[ta][tb]);
-            }
+                    for (int tb = 0; tb < NTN; ++tb) {
+                        const float av = w == 0 ? a[ta].x : w == 1 ? a[ta].y : w == 2 ? a[ta].z : a[ta].w;
+                        const float bv = w == 0 ? b[tb].x : w == 1 ? b[tb].y : w == 2 ? b[tb].z : b[tb].w;
+                        acc[ta][tb] = mfma<MF>(av, bv, acc[ta][tb]);
+                    }
+        }
+    };
+
+    auto compute_tile = [&](int buf, int kt) {
+        if constexpr (SEG == 2) {
+            if (kt >= nk1) { compute(buf, acc2); return; }
+        }
+        compute(buf, acc);
+    };
+    if (nk > 0) {
+        if constexpr (PF == 1) {
+            float4 ra[NA], rb[NB];
+            load_tiles(0, ra, rb);
+            store_tiles(0, ra, rb);
             __syncthreads();
-            if (more) {
-                store_tiles();
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool more = kt + 1 < nk;
+                if (more) load_tiles(kt + 1, ra, rb);
+                compute_tile(0, kt);
+                __syncthreads();
+                if (more) {
+                    store_tiles(0, ra, rb);
+                    __syncthreads();
+                }
+            }
+        } else {
+            // tiles t+1 and t+2 in flight while tile t is multiplied; one barrier per tile
+            float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+            load_tiles(0, ra0, rb0);
+            if (nk > 1) load_tiles(1, ra1, rb1);
+            store_tiles(0, ra0, rb0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt += 2) {
+                if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);
+                compute_tile(0, kt);
+                if (kt + 1 < nk) store_tiles(1, ra1, rb1);
+                __syncthreads();
+                if (kt + 1 >= nk) break;
+                if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+                compute_tile(1, kt + 1);
+                if (kt + 2 < nk) store_tiles(0, ra0, rb0);
                 __syncthreads();
             }
         }
     }
 
+    if constexpr (WK > 1) {
+        // Every wave group publishes its partial accumulators; group wk then owns the accumulator
+        // registers r with r % WK == wk, sums the WK partials of those in group order (deterministic)
+        // and runs the epilogue for them, so the epilogue is spread over all waves.
+        auto reduce = [&](typename AccT<MF>::type(&ac)[NTM][NTN]) {
+            __syncthreads();
+            float *dst = smem + ((size_t)(wk * WM * WN + wrem) * ACCN) * 64 + lane;
+#pragma unroll
+            for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NTN; ++tb)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) dst[((ta * NTN + tb) * NREG + r) * 64] = ac[ta][tb][r];
+            __syncthreads();
+#pragma unroll
+            for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NTN; ++tb)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        if (r % WK != wk) continue;
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int gk = 0; gk < WK; ++gk)
+                            sacc += smem[((size_t)(gk * WM * WN + wrem) * ACCN + (ta * NTN + tb) * NREG + r) * 64 + lane];
+                        ac[ta][tb][r] = sacc;
+                    }
+        };
+        if (nk > 0) {
+            reduce(acc);
+            if constexpr (SEG == 2) reduce(acc2);
+        }
+    }
+
+    if constexpr (C::DBG & 4) { // keep the accumulators live, write nothing
+#pragma unroll
+        for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NTN; ++tb) asm volatile("" ::"v"(acc[ta][tb]));
+        return;
+    }
     // epilogue: C/D map (cdna_hip_programming.md section 3): col = lane % MF,
     // row = 8*(reg>>2) + 4*(lane / MF) + (reg & 3)
 #pragma unroll
     for (int ta = 0; ta < NTM; ++ta)
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
+            if (WK > 1 && r % WK != wk) continue;
             const int m = m0 + wm * TM + ta * MF + 8 * (r >> 2) + 4 * lh + (r & 3);
             if (m >= g.M) continue;
             if constexpr (GATES) {
                 const int u = n0 + wn * MF + li;
                 if (u < g.N) {
                     const float av[4] = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
-                    epi(m, u, av);
+                    if constexpr (PRE) epi(m, u, av, pre[ta][0][r]);
+                    else epi(m, u, av);
                 }
             } else {
 #pragma unroll
                 for (int tb = 0; tb < NTN; ++tb) {
                     const int n = n0 + wn * TN + tb * MF + li;
-                    if (n < g.N) epi(z, m, n, acc[ta][tb][r]);
+                    if (n < g.N) {
+                        if constexpr (PRE) epi(z, m, n, acc[ta][tb][r], SEG == 2 ? acc2[ta][tb][r] : 0.f, pre[ta][tb][r]);
+                        else if constexpr (SEG == 2) epi(z, m, n, acc[ta][tb][r], acc2[ta][tb][r]);
+                        else epi(z, m, n, acc[ta][tb][r]);
+                    }
                 }
             }
         }
 }
 
-template <int MF, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GATES, class Epi>
+template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG = 0>
+__global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_kernel(GemmArgs g, Epi epi)
+{
+    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(g, epi, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems of the same shape class in ONE launch (blockIdx.z = problem):
+// the LSTM steps of different layers on one wavefront diagonal.  More workgroups per launch
+// (two per CU overlap each other's prologue / epilogue) and one kernel boundary per diagonal.
+#define NVQA_MULTI_MAX 4
+template <class Epi> struct MultiArgs {
+    GemmArgs g[NVQA_MULTI_MAX];
+    Epi e[NVQA_MULTI_MAX];
+};
+template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
+__global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_multi_kernel(MultiArgs<Epi> a)
+{
+    const int p = blockIdx.z;
+    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(a.g[p], a.e[p], blockIdx.x, blockIdx.y, 0);
+}
+template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
+inline hipError_t launch_gemm_multi(hipStream_t s, const MultiArgs<Epi> &a, int nprob)
+{
+    const GemmArgs &g = a.g[0]; // all problems share M and N (grid shape)
+    dim3 grid(GATES ? (g.N + C::BN / 4 - 1) / (C::BN / 4) : (g.N + C::BN - 1) / C::BN,
+              (g.M + C::BM - 1) / C::BM, nprob);
+    hipLaunchKernelGGL((gemm_f32_multi_kernel<C, AMODE, BMODE, GATES, Epi, SEG>), grid,
+                       dim3(64 * C::WM * C::WN * C::WK), 0, s, a);
+    return hipGetLastError();
+}
+
+template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG = 0>
 inline hipError_t launch_gemm(hipStream_t s, const GemmArgs &g, const Epi &epi)
 {
     const int ksplit = (g.K + g.kslice - 1) / g.kslice;
-    dim3 grid(GATES ? (g.N + BN / 4 - 1) / (BN / 4) : (g.N + BN - 1) / BN, (g.M + BM - 1) / BM,
-              ksplit < 1 ? 1 : ksplit);
-    hipLaunchKernelGGL((gemm_f32_kernel<MF, BM, BN, BK, WM, WN, AMODE, BMODE, GATES, Epi>), grid,
-                       dim3(64 * WM * WN), 0, s, g, epi);
+    dim3 grid(GATES ? (g.N + C::BN / 4 - 1) / (C::BN / 4) : (g.N + C::BN - 1) / C::BN,
+              (g.M + C::BM - 1) / C::BM, ksplit < 1 ? 1 : ksplit);
+    hipLaunchKernelGGL((gemm_f32_kernel<C, AMODE, BMODE, GATES, Epi, SEG>), grid,
+                       dim3(64 * C::WM * C::WN * C::WK), 0, s, g, epi);
     return hipGetLastError();
 }
 

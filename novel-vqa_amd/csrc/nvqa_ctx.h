@@ -68,7 +68,11 @@ struct nvqa_ctx {
     nvqa_dims d;
     nvqa_layout lo;
     int device = 0;
-    hipStream_t s = nullptr;
+    hipStream_t s = nullptr;                     // main stream (also the layer-0 recurrence chain)
+    hipStream_t sl[NVQA_MAX_LAYERS] = {};        // recurrence chains of layers >= 1 (high priority)
+    hipStream_t sb = nullptr, sb2 = nullptr;     // bulk streams: time-chunked weight gradients (low priority)
+    std::vector<hipEvent_t> evF[NVQA_MAX_LAYERS], evB[NVQA_MAX_LAYERS]; // per layer, per step
+    hipEvent_t evHead = nullptr, evBulk = nullptr, evBulk2 = nullptr, evStart = nullptr;
     int TS = 0; // recurrent steps: arch1 T, arch2 T+2
 
     // parameters / gradients / RMSprop mean-square (internal layout = ABI layout with the
@@ -93,7 +97,7 @@ struct nvqa_ctx {
     float *qd = nullptr, *vd = nullptr, *qc = nullptr, *ic = nullptr, *zd = nullptr;
     float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
     float *dqc = nullptr, *dic = nullptr;
-    float *colpart = nullptr, *slabs = nullptr;
+    float *colpart = nullptr, *slabs = nullptr, *slabs2 = nullptr;
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
     float *h_loss = nullptr; // pinned
