@@ -115,6 +115,17 @@ struct EpiResort {
     }
 };
 
+// arch2 head: d(hd) -> Dropout backward -> dL/dh of the top layer at step tmax
+struct EpiHead2 {
+    float *dH;
+    int R;
+    Drop dr;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        dH[(size_t)m * R + n] = dr.scale(NVQA_SITE_Q, (uint64_t)m * R + n) * v;
+    }
+};
+
 // d(input of layer l) -> inter-layer Dropout backward (misc/LSTM.lua:37); rows are (t, r)
 struct EpiDU {
     float *out; // [T*B][R]
@@ -192,6 +203,7 @@ struct EpiLstmBwd {
     const float *c_prev, *c;   // [B][R] cell before / after step s
     float *dc;                 // [B][R] carried cell gradient (in: dL/dc_s from s+1, out: dL/dc_{s-1})
     const float *dh_ext, *dh_ext2; // optional extra dL/dh_s terms (upper layer, head)
+    const int *tlast;              // optional: dh_ext2 enters only at step *tlast (arch2: tmax-1)
     const int *nrows;
     int R;
     // two-accumulator form (SEG == 2): v2 = (dG^{l+1}_s W_i2h^{l+1})[m][u], the gradient reaching
@@ -207,7 +219,7 @@ struct EpiLstmBwd {
         Pre q;
         q.ig = gates[gi]; q.fg = gates[gi + R]; q.og = gates[gi + 2 * R]; q.gg = gates[gi + 3 * R];
         q.c = c[si]; q.cp = c_prev[si]; q.dc = dc[si];
-        q.dhx = (dh_ext ? dh_ext[si] : 0.f) + (dh_ext2 ? dh_ext2[si] : 0.f);
+        q.dhx = (dh_ext ? dh_ext[si] : 0.f) + ((dh_ext2 && (!tlast || *tlast == s)) ? dh_ext2[si] : 0.f);
         q.dscale = has_upper ? dr.scale(NVQA_SITE_LSTM, ((((uint64_t)lm1) * B + sort_idx[m]) * T + s) * R + u) : 0.f;
         q.nr = *nrows;
         return q;

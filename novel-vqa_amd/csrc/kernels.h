@@ -262,7 +262,8 @@ __global__ void k_reduce_slabs(const float *slabs, int S, size_t n4, float4 *C)
 // ---------------------------------------------------------------------------------
 #define NVQA_EB_ROWS 16
 __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, const int32_t *sort_idx,
-                          int NP /*T*B*/, int B, int T, int V, int E, Drop dr, float *dWeT /*[V][E]*/)
+                          int NP /*T*B*/, int B, int T, int V, int E, Drop dr, float *dWeT /*[V][E]*/,
+                          int plain /* 1: nn.LookupTable (arch2): the row gradient is dX itself */)
 {
     extern __shared__ float acc[]; // [waves][16][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -283,14 +284,84 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
             const int t = kk / B, r = kk % B;
             const uint64_t base = ((uint64_t)sort_idx[r] * T + t) * E;
             for (int e = lane; e < E; e += 64) {
-                const float x = X[(size_t)kk * E + e];
-                const float dp = dr.scale(NVQA_SITE_EMB, base + e) * (dX[(size_t)kk * E + e] * (1.0f - x * x));
+                float dp = dX[(size_t)kk * E + e];
+                if (!plain) {
+                    const float x = X[(size_t)kk * E + e];
+                    dp = dr.scale(NVQA_SITE_EMB, base + e) * (dp * (1.0f - x * x));
+                }
                 my[row * E + e] += dp;
             }
         }
     }
     const int nr = min(NVQA_EB_ROWS, V - v0);
     for (int i = lane; i < nr * E; i += 64) dWeT[(size_t)v0 * E + i] = my[i];
+}
+
+// ---------------------------------------------------------------------------------
+// arch2 (003_train_vqa_arch2/misc/Encoder_lstm.lua:152-227): the encoder runs T+2 steps;
+// step 0 = projected image, step 1 = START token (row V of the lookup table), step t >= 2 =
+// token t-2 with null (0) rewritten to token 1 (:197).  It stops at the first all-null time
+// row (:185-189): tmax = number of steps run.  One workgroup.
+// ---------------------------------------------------------------------------------
+__global__ void k_arch2_tmax(const int32_t *tok, int B, int T, int32_t *nrows /*[T+2]*/, int32_t *tinfo /*[2]: tmax, tmax-1*/,
+                             int32_t *sort_idx, int32_t *sort_inv)
+{
+    __shared__ int colany[256];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) colany[t] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * T; i += blockDim.x)
+        if (tok[i] != 0) colany[i % T] = 1; // benign race: every writer stores 1
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { sort_idx[b] = b; sort_inv[b] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tmax = 2;
+        for (int t = 0; t < T; ++t) {
+            if (!colany[t]) break;
+            tmax = t + 3;
+        }
+        tinfo[0] = tmax;
+        tinfo[1] = tmax - 1;
+        for (int t = 0; t < T + 2; ++t) nrows[t] = t < tmax ? B : 0;
+    }
+}
+
+// lookup-table gather for steps >= 1 (Encoder_lstm.lua:177-203); step 0 rows are written by the
+// cnn_projection GEMM.  One wave per (step, sample) row.
+__global__ void k_arch2_embed(const int32_t *tok, const int32_t *tinfo, const float *Wlk, int B, int T, int V, int E,
+                              float *X, int32_t *ptok)
+{
+    const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    const int TS = T + 2;
+    if (row >= TS * B) return;
+    const int t = row / B, b = row % B;
+    if (t == 0) {
+        if (lane == 0) ptok[row] = -1;
+        return;
+    }
+    float4 *x4 = reinterpret_cast<float4 *>(X + (size_t)row * E);
+    if (t >= tinfo[0]) {
+        for (int i = lane; i < E / 4; i += 64) x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) ptok[row] = -1;
+        return;
+    }
+    int w = V; // START = token V+1
+    if (t >= 2) {
+        w = tok[(size_t)b * T + (t - 2)];
+        w = (w == 0 ? 1 : w) - 1;
+    }
+    if (lane == 0) ptok[row] = w;
+    const float4 *w4 = reinterpret_cast<const float4 *>(Wlk + (size_t)w * E);
+    for (int i = lane; i < E / 4; i += 64) x4[i] = w4[i];
+}
+
+// head input: Dropout(h^L at step tmax) (003_.../002_train_baseline.lua:162-164, Encoder_lstm.lua:224)
+__global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int32_t *tinfo, int B, int R, Drop dr, float *hd)
+{
+    const int b = blockIdx.x;
+    const float *src = Htop + ((size_t)tinfo[0] * B + b) * R;
+    for (int j = threadIdx.x; j < R; j += blockDim.x)
+        hd[(size_t)b * R + j] = dr.scale(NVQA_SITE_Q, (uint64_t)b * R + j) * src[j];
 }
 
 // ---------------------------------------------------------------------------------

@@ -209,6 +209,7 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     NVQA_TRY(dalloc(&c->sort_inv, B));
     NVQA_TRY(dalloc(&c->nrows, TS));
     NVQA_TRY(dalloc(&c->ptok, TB));
+    NVQA_TRY(dalloc(&c->tinfo, 2));
     NVQA_TRY(dalloc(&c->X0, TB * E));
     NVQA_TRY(dalloc(&c->dX0, TB * E));
     for (size_t l = 0; l < L; ++l) {
@@ -260,7 +261,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     (void)hipDeviceSynchronize();
     prof_collect(c);
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
-                    c->nrows, c->ptok, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
+                    c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
                     c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->slabs2,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
     for (void *p : ptrs)
@@ -513,7 +514,8 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
             e.c = c->Cs[l] + (size_t)(s + 1) * B * R;
             e.dc = c->dCT + (size_t)l * B * R;
             e.dh_ext = nullptr;
-            e.dh_ext2 = last ? c->dHT + (size_t)l * B * R : nullptr;
+            e.dh_ext2 = (last || d.arch == NVQA_ARCH2) ? c->dHT + (size_t)l * B * R : nullptr;
+            e.tlast = d.arch == NVQA_ARCH2 ? c->tinfo + 1 : nullptr;
             e.nrows = c->nrows + s;
             e.R = R;
             e.sort_idx = c->sort_idx; e.B = B; e.T = TS; e.s = s; e.lm1 = l; e.dr = dr;
@@ -642,10 +644,84 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
         const int waves = 4;
         const int blocks = (V + waves * NVQA_EB_ROWS - 1) / (waves * NVQA_EB_ROWS);
         hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
-                           c->ptok, c->X0, dX0, c->sort_idx, TB, B, T, V, E, dr, G + c->lo.w_e);
+                           c->ptok, c->X0, dX0, c->sort_idx, TB, B, T, V, E, dr, G + c->lo.w_e, 0);
     }
     NVQA_HIP(hipGetLastError());
     NVQA_TRY(colsum(c, G + c->lo.w_e, V, E, E, G + c->lo.b_e, nullptr));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// arch2 (003_train_vqa_arch2/002_train_baseline.lua:277-333, misc/Encoder_lstm.lua)
+// ------------------------------------------------------------------------------------
+static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argmax)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, T = d.T, R = d.R, L = d.L, E = d.E, I = d.I, A = d.A, TS = c->TS, TB = TS * B;
+    {
+        ProfScope ps(c, PF_ASSEMBLE);
+        hipLaunchKernelGGL(k_arch2_tmax, dim3(1), dim3(256), 0, c->s, c->tok, B, T, c->nrows, c->tinfo, c->sort_idx, c->sort_inv);
+    }
+    {   // x_1 = cnn_projection(fv_im): Linear(I, E), no dropout / non-linearity (:166,308) -> step-0 rows of X0
+        ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * E * I, ((double)B * I + (double)E * I) * 4);
+        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->img, I, c->P + c->lo.w_p, I, B, E, I),
+                                       EpiBias2{c->X0, E, c->P + c->lo.b_p, nullptr})));
+    }
+    {
+        ProfScope ps(c, PF_EMB_FWD, 0, 2.0 * TB * E * 4);
+        hipLaunchKernelGGL(k_arch2_embed, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->tinfo, c->P + c->lo.w_lk, B, T, d.V, E, c->X0, c->ptok);
+    }
+    NVQA_HIP(hipGetLastError());
+    NVQA_TRY(lstm_forward(c, dr));
+    {
+        ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * R * 4);
+        hipLaunchKernelGGL(k_arch2_head_prep, dim3(B), dim3(256), 0, c->s, c->Hs[L - 1], c->tinfo, B, R, dr, c->qd);
+    }
+    {   // scores = Linear(R, A)(Dropout(h))
+        ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * A * R, ((double)B * R + (double)A * R) * 4);
+        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->qd, R, c->P + c->lo.w_o, R, B, A, R),
+                                       EpiBias2{c->scores, A, c->P + c->lo.b_o, nullptr})));
+    }
+    {
+        ProfScope ps(c, PF_SOFTMAX_CE, 0, 2.0 * B * A * 4);
+        hipLaunchKernelGGL(k_softmax_ce, dim3((B + 3) / 4), dim3(256), 0, c->s, c->scores,
+                           train ? c->lab : (const int32_t *)nullptr, B, A, train ? c->dscores : (float *)nullptr,
+                           c->rowloss, want_argmax ? c->argmax : (int32_t *)nullptr);
+        if (train) hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(256), 0, c->s, c->rowloss, B, c->d_loss);
+    }
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+static int arch2_backward(nvqa_ctx *c, const Drop &dr)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, R = d.R, L = d.L, E = d.E, I = d.I, A = d.A, V = d.V, TS = c->TS, TB = TS * B;
+    float *G = c->G;
+    // only the top layer's h at step tmax receives a gradient from the head (Encoder_lstm.lua:238-239)
+    NVQA_HIP(hipMemsetAsync(c->dCT, 0, (size_t)L * B * R * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->dHT, 0, (size_t)L * B * R * 4, c->s));
+    {
+        ProfScope ps(c, PF_GEMM_HEAD_BWD, 4.0 * B * A * R, (2.0 * A * R + 2.0 * B * A) * 4);
+        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->qd, R, A, R, B), EpiStore{G + c->lo.w_o, R, 0})));
+        NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, R, B, R, A),
+                                       EpiHead2{c->dHT + (size_t)(L - 1) * B * R, R, dr})));
+    }
+    NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
+    NVQA_TRY(lstm_backward(c, dr, c->dX0));
+    {   // cnn_projection:backward (002_train_baseline.lua:322): dW_p = dx_1^T fv_im, db_p = colsum(dx_1)
+        ProfScope ps(c, PF_GEMM_HEAD_BWD, 2.0 * B * E * I, ((double)B * (E + I) + (double)E * I) * 4);
+        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dX0, E, c->img, I, E, I, B), EpiStore{G + c->lo.w_p, I, 0})));
+    }
+    NVQA_TRY(colsum(c, c->dX0, B, E, E, G + c->lo.b_p, nullptr));
+    {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
+        ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)(V + 1) * E) * 4);
+        const int waves = 4;
+        const int blocks = (V + 1 + waves * NVQA_EB_ROWS - 1) / (waves * NVQA_EB_ROWS);
+        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
+                           c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
+    }
+    NVQA_HIP(hipGetLastError());
     return 0;
 }
 
@@ -659,8 +735,8 @@ static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
         NVQA_TRY(arch1_forward(c, dr, true, false));
         NVQA_TRY(arch1_backward(c, dr));
     } else {
-        set_error("arch2 step is not built yet");
-        return -3;
+        NVQA_TRY(arch2_forward(c, dr, true, false));
+        NVQA_TRY(arch2_backward(c, dr));
     }
     c->have_grads = true;
     NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
@@ -734,8 +810,7 @@ extern "C" int nvqa_forward(nvqa_ctx *c, int32_t n, const int32_t *tokens, const
     if (c->d.arch == NVQA_ARCH1) {
         NVQA_TRY(arch1_forward(c, dr, false, true));
     } else {
-        set_error("arch2 forward is not built yet");
-        return -3;
+        NVQA_TRY(arch2_forward(c, dr, false, true));
     }
     NVQA_HIP(hipStreamSynchronize(c->s));
     if (scores_out) NVQA_HIP(hipMemcpy(scores_out, c->scores, (size_t)n * c->d.A * 4, hipMemcpyDeviceToHost));

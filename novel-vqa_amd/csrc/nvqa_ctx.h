@@ -85,6 +85,7 @@ struct nvqa_ctx {
     float *img = nullptr;
     int64_t *qinds = nullptr;
     int32_t *sort_idx = nullptr, *sort_inv = nullptr, *nrows = nullptr, *ptok = nullptr;
+    int32_t *tinfo = nullptr; // arch2: {tmax, tmax-1}
 
     // activations
     float *X0 = nullptr, *dX0 = nullptr;       // [TS*B][E] layer-0 inputs and their gradient

@@ -1,0 +1,50 @@
+"""HIP path against the committed golden vectors (tests/golden/*.npz, made by make_golden.py
+from the float64 oracle) -- nothing under oracle/ is imported here except the input generator
+for the mid-size case, whose inputs are regenerated from the seed."""
+import os
+
+import numpy as np
+import pytest
+
+from util import gdims, relmax
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["arch1_tiny", "arch2_tiny", "arch1_mid"])
+def test_gpu_matches_golden(pkg, orc, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = orc.make_dims(*[int(v) for v in g["dims"]])
+    mode, seed, step = (int(v) for v in g["dropout"])
+    if "params" in g:
+        params, tok, lens, img, lab = g["params"], g["tokens"], g["lengths"], g["img"], g["labels"]
+    else:
+        params = orc.synth_params(d)
+        tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    loss = ctx.step(tok, lens if d.arch == 1 else None, img, lab, pkg.binding.Dropout(mode, 0.5, seed, step))
+    grads = ctx.get_grads()
+    assert abs(loss - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert relmax(grads[:64], g["grad_head"]) < 1e-3 and relmax(grads[-64:], g["grad_tail"]) < 1e-3
+    lo = orc.layout(d)
+    for k, s, a in zip(g["grad_seg_names"], g["grad_seg_sum"], g["grad_seg_abs"]):
+        o_, n_ = lo[str(k)]
+        assert abs(grads[o_:o_ + n_].astype(np.float64).sum() - s) < 1e-3 * a + 1e-9, k
+    if "grads" in g:
+        assert relmax(grads, g["grads"]) < 1e-4
+    ctx.rmsprop_update(3e-4, 0.99, 1e-8, 1e-4 if d.arch == 2 else 0.0, 10.0)
+    x = ctx.get_params()
+    assert relmax(x[:64], g["params_after_head"]) < 1e-6 and relmax(x[-64:], g["params_after_tail"]) < 1e-6
+    scores, argmax = ctx.forward(tok, lens if d.arch == 1 else None, img)
+    ctx.close()
+    # forward ran AFTER the update above: compare against a fresh context instead
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    scores, argmax = ctx.forward(tok, lens if d.arch == 1 else None, img)
+    assert relmax(scores, g["eval_scores"]) < 1e-4
+    top2 = np.sort(g["eval_scores"], 1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * np.abs(top2[:, 1])
+    assert np.array_equal(argmax[clear], g["eval_argmax"][clear])
+    ctx.close()
