@@ -137,6 +137,25 @@ int nvqa_step_indices(nvqa_ctx *ctx, const int64_t *qinds, const nvqa_dropout *d
 int nvqa_comm_unique_id(void *id_out /* NVQA_COMM_ID_BYTES */);
 int nvqa_comm_init(nvqa_ctx *ctx, int rank, int world, const void *id);
 
+/* ---- VGG-16 fc7 feature extractor (002_train_vqa_arch1/001_prepro_img_vgg.lua) ---- */
+/* Forward only.  width_div = 1 and input_hw = 224 is the real 16-layer VGG (channels
+ * 64..512, fc 4096); other values shrink it for tests.  Replaces loadcaffe.load +
+ * net:forward + net.modules[38].output (:36-37,109-110). */
+typedef struct nvqa_vgg nvqa_vgg;
+int nvqa_vgg16_create(int device, int width_div, int input_hw, int max_batch, nvqa_vgg **out);
+int nvqa_vgg16_destroy(nvqa_vgg *vgg);
+size_t nvqa_vgg16_weight_count(const nvqa_vgg *vgg);
+int nvqa_vgg16_feature_dim(const nvqa_vgg *vgg);
+/* One flat vector in Caffe order and layout: per conv W [Cout][Cin][3][3], b [Cout];
+ * fc6 W [F][C5*S*S] (CHW-flattened input), b [F]; fc7 W [F][F], b [F]. */
+int nvqa_vgg16_set_weights(nvqa_vgg *vgg, const float *flat);
+/* images: n x 3 x hw x hw as loadim returns them (BGR planes, mean-subtracted, :65-70);
+ * feats_out: n x F = post-ReLU fc7. */
+int nvqa_vgg16_fc7(nvqa_vgg *vgg, const float *images, int n, float *feats_out);
+/* loadim's arithmetic (:50,65-69): bilinear scale of RGB [0,1] planes n x 3 x H x W to hw x hw,
+ * x255, RGB->BGR, mean subtraction.  out: n x 3 x hw x hw. */
+int nvqa_vgg16_preprocess(nvqa_vgg *vgg, const float *rgb, int n, int H, int W, float *out);
+
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event timing of kernel groups on the stream they are launched on.
  * enable=1 brackets every launch with events (slows the step; bench.py uses a

@@ -13,6 +13,7 @@
 // Operand layouts (all row-major storage, ld in floats, ld % 4 == 0):
 //   A_KC: A stored [M][K]  (k contiguous)     activations / dY for dgrad
 //   A_MC: A stored [K][M]  (m contiguous)     dY^T for wgrad, without a transpose pass
+//   A_IM2COL: implicit im2col of an NHWC tensor (3x3 conv), K-contiguous like A_KC
 //   B_KC: B stored [N][K]  (k contiguous)     Torch nn.Linear weight [out][in] in forward
 //   B_NC: B stored [K][N]  (n contiguous)     the same weight in dgrad, activations in wgrad
 // LDS images are k-major ([BK][BM+pad]) so that a wave's MFMA operand read is 32 (or 16)
@@ -37,7 +38,7 @@
 namespace nvqa {
 template <class E> struct EpiTraits; // epilogues.h
 
-enum { A_KC = 0, A_MC = 1 };
+enum { A_KC = 0, A_MC = 1, A_IM2COL = 2 };
 enum { B_KC = 0, B_NC = 1 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -57,6 +58,9 @@ struct GemmArgs {
     const float *A2;
     const float *B2;
     int lda2, ldb2, K2;
+    // A_IM2COL: A is an NHWC activation [n][cH][cW][cC]; row m = output pixel (n, y, x) of a 3x3,
+    // stride-1, pad-1 convolution, k = (ky*3 + kx)*cC + ci (cC % 4 == 0): implicit GEMM, no im2col buffer
+    int cH, cW, cC;
 };
 
 template <int MF> struct AccT;
@@ -122,9 +126,9 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     // K-contiguous operands: LDS image [rows][BK], chunk-swizzled, read with ds_read_b128.
     // M/N-contiguous operands: LDS image [BK][rows + 4], read with ds_read_b32 (the 4 floats of a
     // q step sit 4 rows apart for the KI lane groups: (4*LD) % 32 == 16 keeps MF=16 conflict-free).
-    constexpr int LDA = AMODE == A_KC ? BK : BM + 4;
+    constexpr int LDA = AMODE != A_MC ? BK : BM + 4;
     constexpr int LDB = BMODE == B_KC ? BK : BN + 4;
-    constexpr int A_FL = AMODE == A_KC ? BM * BK : BK * LDA;
+    constexpr int A_FL = AMODE != A_MC ? BM * BK : BK * LDA;
     constexpr int B_FL = BMODE == B_KC ? BN * BK : BK * LDB;
     constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
     constexpr int NA = (A_F4 + NT - 1) / NT, NB = (B_F4 + NT - 1) / NT;
@@ -216,6 +220,17 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
                     const int row = f / (BK / 4), kq = f % (BK / 4);
                     const int m = m0 + row, k = k0 + 4 * kq;
                     if (m < mlim && k < kend) v = *reinterpret_cast<const float4 *>(gA + (size_t)m * glda + k);
+                } else if (AMODE == A_IM2COL) {
+                    const int row = f / (BK / 4), kq = f % (BK / 4);
+                    const int m = m0 + row, k = k0 + 4 * kq;
+                    if (m < mlim && k < kend) {
+                        const int hw = g.cH * g.cW;
+                        const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
+                        const int tap = k / g.cC, ci = k - tap * g.cC, ky = tap / 3, kx = tap - ky * 3;
+                        const int iy = y + ky - 1, ix = x + kx - 1;
+                        if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
+                            v = *reinterpret_cast<const float4 *>(gA + (((size_t)n * g.cH + iy) * g.cW + ix) * g.cC + ci);
+                    }
                 } else {
                     const int kr = f / (BM / 4), mq = f % (BM / 4);
                     const int k = k0 + kr, m = m0 + 4 * mq;
@@ -258,7 +273,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         for (int j = 0; j < NA; ++j) {
             const int f = tid + j * NT;
             if (A_F4 % NT == 0 || f < A_F4) {
-                if (AMODE == A_KC) {
+                if (AMODE != A_MC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
                     *reinterpret_cast<float4 *>(&As[row * BK + 4 * swz_chunk<BK>(row, kq)]) = ra[j];
                 } else {
@@ -291,7 +306,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
 #pragma unroll
             for (int t = 0; t < NTM; ++t) {
                 const int row = wm * TM + t * MF + li;
-                if constexpr (AMODE == A_KC) {
+                if constexpr (AMODE != A_MC) {
                     a[t] = *reinterpret_cast<const float4 *>(&As[row * BK + 4 * swz_chunk<BK>(row, KI * q + lh)]);
                 } else {
                     const float *p = &As[(QK * q + 4 * lh) * LDA + row];

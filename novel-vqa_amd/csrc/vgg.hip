@@ -1,0 +1,322 @@
+// vgg.hip -- VGG-16 fc7 feature extractor (forward only) on gfx950.
+//
+// Replaces 002_train_vqa_arch1/001_prepro_img_vgg.lua: loadcaffe.load(...,'cudnn') + net:forward(ims)
+// + net.modules[38].output (:36-37,109-110), i.e. 13 conv3x3/ReLU, 5 max-pools, fc6+ReLU, fc7+ReLU
+// (module 38 = the Dropout after fc7's ReLU, identity in evaluate mode => post-ReLU fc7), and the
+// per-image preprocessing of loadim (:47-71).
+//
+// Design: activations NHWC (channels padded to a multiple of 4), every convolution is an implicit
+// GEMM on the fp32 MFMA template of gemm_f32.h (A_IM2COL: M = n*H*W output pixels, N = C_out,
+// K = 9*C_in), bias+ReLU fused in the epilogue; fc6/fc7 are split-K GEMMs (M = batch is small, the
+// 411 MB fc6 weight stream is the cost) with bias+ReLU fused into the slab reduction.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/nvqa.h"
+#include "gemm_f32.h"
+#include "nvqa_ctx.h"
+
+using namespace nvqa;
+
+namespace {
+
+const int kConvCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+const int kPoolAfter[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
+
+struct EpiBiasRelu {
+    float *C;
+    int ldc;
+    const float *b;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        C[(size_t)m * ldc + n] = fmaxf(v + b[n], 0.0f);
+    }
+};
+struct EpiSlab {
+    float *C;
+    int ldc;
+    size_t slab;
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v) const { C[(size_t)z * slab + (size_t)m * ldc + n] = v; }
+};
+
+// NCHW [n][3][H][W] -> NHWC with 4 channels (4th = 0)
+__global__ void k_nchw_to_nhwc4(const float *in, int n, int H, int W, float4 *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t hw = (size_t)H * W;
+    if (i >= n * hw) return;
+    const size_t img = i / hw, p = i % hw;
+    const float *src = in + img * 3 * hw + p;
+    out[i] = make_float4(src[0], src[hw], src[2 * hw], 0.f);
+}
+
+// 2x2 max pool, stride 2, NHWC, C % 4 == 0
+__global__ void k_maxpool2_nhwc(const float4 *in, int n, int H, int W, int C4, float4 *out)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * Ho * Wo * C4;
+    if (i >= total) return;
+    const int c = i % C4;
+    size_t p = i / C4;
+    const int x = p % Wo; p /= Wo;
+    const int y = p % Ho; const size_t img = p / Ho;
+    const float4 *b = in + ((img * H + 2 * y) * W + 2 * x) * C4 + c;
+    const float4 a0 = b[0], a1 = b[C4], a2 = b[(size_t)W * C4], a3 = b[(size_t)W * C4 + C4];
+    float4 o;
+    o.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+    o.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
+    o.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
+    o.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
+    out[i] = o;
+}
+
+// sum of split-K slabs + bias + ReLU (fc6 / fc7)
+__global__ void k_fc_finish(const float *slabs, int S, int M, int N, const float *bias, float *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[(size_t)z * M * N + i];
+    out[i] = fmaxf(s + bias[i % N], 0.0f);
+}
+
+// loadim (001_prepro_img_vgg.lua:47-71): bilinear scale to 224x224 ignoring aspect, x255, RGB -> BGR,
+// per-channel mean subtraction.  in [n][3][H][W] RGB in [0,1]; out [n][3][224][224] (BGR planes).
+// The exact interpolation of Torch's image.scale is not pinned by the reference; align-corners
+// bilinear is used and said so in DESIGN.md.
+__global__ void k_vgg_preprocess(const float *in, int n, int H, int W, int S, float *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * 3 * S * S;
+    if (i >= total) return;
+    const int x = i % S, y = (i / S) % S, c = (i / ((size_t)S * S)) % 3;
+    const size_t img = i / ((size_t)3 * S * S);
+    const int src_c = 2 - c; // output plane 0 = B = input plane 2
+    const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+    const float fy = S > 1 ? (float)y * (float)(H - 1) / (float)(S - 1) : 0.f;
+    const float fx = S > 1 ? (float)x * (float)(W - 1) / (float)(S - 1) : 0.f;
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float *p = in + (img * 3 + src_c) * (size_t)H * W;
+    const float v = (1.f - wy) * ((1.f - wx) * p[(size_t)y0 * W + x0] + wx * p[(size_t)y0 * W + x1]) +
+                    wy * ((1.f - wx) * p[(size_t)y1 * W + x0] + wx * p[(size_t)y1 * W + x1]);
+    out[i] = v * 255.0f - mean;
+}
+
+typedef Cfg<32, 128, 128, 32, 2, 2, 1, 2> CfgConv;   // C_out >= 128
+typedef Cfg<32, 128, 64, 32, 2, 2, 1, 2> CfgConv64;  // C_out <= 64
+typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgFc;
+
+} // namespace
+
+struct nvqa_vgg {
+    int device = 0, div = 1, hw = 224, max_batch = 0;
+    hipStream_t s = nullptr;
+    int cin[13], cinp[13], cout[13], coutp[13];
+    int c5 = 0, s5 = 0, fcin = 0, F = 0;
+    size_t w_off[15], b_off[15], flat_total = 0; // offsets in the ABI (Caffe-layout) weight vector
+    float *Wc[13] = {}, *bc[13] = {};           // repacked conv weights [Cout][3][3][Cin_pad], bias
+    float *Wf[2] = {}, *bf[2] = {};             // fc6 [F][s5*s5*c5p] (columns in NHWC order), fc7 [F][F]
+    float *img = nullptr, *act[2] = {}, *slabs = nullptr, *fc6o = nullptr, *fc7o = nullptr, *nhwc_in = nullptr;
+    size_t act_floats = 0;
+    bool have_weights = false;
+};
+
+static int vgg_layout(nvqa_vgg *v)
+{
+    size_t off = 0;
+    int cin = 3;
+    for (int i = 0; i < 13; ++i) {
+        v->cin[i] = cin;
+        v->cinp[i] = (cin + 3) / 4 * 4;
+        v->cout[i] = std::max(1, kConvCout[i] / v->div);
+        v->coutp[i] = (v->cout[i] + 3) / 4 * 4;
+        v->w_off[i] = off; off += (size_t)v->cout[i] * cin * 9;
+        v->b_off[i] = off; off += v->cout[i];
+        cin = v->cout[i];
+    }
+    v->c5 = cin;
+    v->s5 = v->hw / 32;
+    v->fcin = v->c5 * v->s5 * v->s5;
+    v->F = std::max(4, 4096 / v->div);
+    v->w_off[13] = off; off += (size_t)v->F * v->fcin;
+    v->b_off[13] = off; off += v->F;
+    v->w_off[14] = off; off += (size_t)v->F * v->F;
+    v->b_off[14] = off; off += v->F;
+    v->flat_total = off;
+    return 0;
+}
+
+extern "C" int nvqa_vgg16_create(int device, int width_div, int input_hw, int max_batch, nvqa_vgg **out)
+{
+    if (!out) { set_error("out is NULL"); return -1; }
+    *out = nullptr;
+    if (width_div < 1 || 64 % width_div != 0 || input_hw < 32 || input_hw % 32 || max_batch < 1) {
+        set_error("bad VGG config (width_div=%d must divide 64, input_hw=%d must be a multiple of 32, max_batch=%d)",
+                  width_div, input_hw, max_batch);
+        return -1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device available (libnvqa has no CPU fallback)"); return -2; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range", device); return -1; }
+    NVQA_HIP(hipSetDevice(device));
+    nvqa_vgg *v = new nvqa_vgg();
+    v->device = device; v->div = width_div; v->hw = input_hw; v->max_batch = max_batch;
+    vgg_layout(v);
+    NVQA_HIP(hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking));
+    for (int i = 0; i < 13; ++i) {
+        NVQA_HIP(hipMalloc((void **)&v->Wc[i], (size_t)v->cout[i] * 9 * v->cinp[i] * 4));
+        NVQA_HIP(hipMalloc((void **)&v->bc[i], (size_t)v->cout[i] * 4));
+    }
+    const int c5p = (v->c5 + 3) / 4 * 4;
+    NVQA_HIP(hipMalloc((void **)&v->Wf[0], (size_t)v->F * v->s5 * v->s5 * c5p * 4));
+    NVQA_HIP(hipMalloc((void **)&v->Wf[1], (size_t)v->F * v->F * 4));
+    NVQA_HIP(hipMalloc((void **)&v->bf[0], (size_t)v->F * 4));
+    NVQA_HIP(hipMalloc((void **)&v->bf[1], (size_t)v->F * 4));
+    const size_t px = (size_t)max_batch * input_hw * input_hw;
+    v->act_floats = px * std::max(4, v->coutp[0]); // largest activation: conv1 output at full resolution
+    NVQA_HIP(hipMalloc((void **)&v->img, px * 3 * 4));
+    NVQA_HIP(hipMalloc((void **)&v->nhwc_in, px * 4 * 4));
+    NVQA_HIP(hipMalloc((void **)&v->act[0], v->act_floats * 4));
+    NVQA_HIP(hipMalloc((void **)&v->act[1], v->act_floats * 4));
+    NVQA_HIP(hipMalloc((void **)&v->slabs, (size_t)16 * max_batch * v->F * 4));
+    NVQA_HIP(hipMalloc((void **)&v->fc6o, (size_t)max_batch * v->F * 4));
+    NVQA_HIP(hipMalloc((void **)&v->fc7o, (size_t)max_batch * v->F * 4));
+    *out = v;
+    return 0;
+}
+
+extern "C" int nvqa_vgg16_destroy(nvqa_vgg *v)
+{
+    if (!v) return 0;
+    (void)hipSetDevice(v->device);
+    (void)hipStreamSynchronize(v->s);
+    for (int i = 0; i < 13; ++i) { (void)hipFree(v->Wc[i]); (void)hipFree(v->bc[i]); }
+    for (int i = 0; i < 2; ++i) { (void)hipFree(v->Wf[i]); (void)hipFree(v->bf[i]); (void)hipFree(v->act[i]); }
+    (void)hipFree(v->img); (void)hipFree(v->nhwc_in); (void)hipFree(v->slabs); (void)hipFree(v->fc6o); (void)hipFree(v->fc7o);
+    (void)hipStreamDestroy(v->s);
+    delete v;
+    return 0;
+}
+
+extern "C" size_t nvqa_vgg16_weight_count(const nvqa_vgg *v) { return v ? v->flat_total : 0; }
+extern "C" int nvqa_vgg16_feature_dim(const nvqa_vgg *v) { return v ? v->F : 0; }
+
+// weights: one flat vector in Caffe order and layout -- for each conv W [Cout][Cin][3][3], b [Cout];
+// fc6 W [F][C5*S*S] (columns in CHW order), b; fc7 W [F][F], b.
+extern "C" int nvqa_vgg16_set_weights(nvqa_vgg *v, const float *flat)
+{
+    if (!v || !flat) { set_error("NULL argument"); return -1; }
+    NVQA_HIP(hipSetDevice(v->device));
+    NVQA_HIP(hipStreamSynchronize(v->s));
+    for (int i = 0; i < 13; ++i) {
+        const int co = v->cout[i], ci = v->cin[i], cp = v->cinp[i];
+        std::vector<float> w((size_t)co * 9 * cp, 0.f);
+        const float *src = flat + v->w_off[i];
+        for (int o = 0; o < co; ++o)
+            for (int c = 0; c < ci; ++c)
+                for (int t = 0; t < 9; ++t) w[((size_t)o * 9 + t) * cp + c] = src[((size_t)o * ci + c) * 9 + t];
+        NVQA_HIP(hipMemcpy(v->Wc[i], w.data(), w.size() * 4, hipMemcpyHostToDevice));
+        NVQA_HIP(hipMemcpy(v->bc[i], flat + v->b_off[i], (size_t)co * 4, hipMemcpyHostToDevice));
+    }
+    {   // fc6: CHW-flattened columns -> (y, x, c_padded) = the NHWC pool5 activation
+        const int c5 = v->c5, c5p = (c5 + 3) / 4 * 4, S = v->s5, F = v->F;
+        std::vector<float> w((size_t)F * S * S * c5p, 0.f);
+        const float *src = flat + v->w_off[13];
+        for (int f = 0; f < F; ++f)
+            for (int c = 0; c < c5; ++c)
+                for (int p = 0; p < S * S; ++p) w[((size_t)f * S * S + p) * c5p + c] = src[(size_t)f * v->fcin + (size_t)c * S * S + p];
+        NVQA_HIP(hipMemcpy(v->Wf[0], w.data(), w.size() * 4, hipMemcpyHostToDevice));
+        NVQA_HIP(hipMemcpy(v->bf[0], flat + v->b_off[13], (size_t)F * 4, hipMemcpyHostToDevice));
+        NVQA_HIP(hipMemcpy(v->Wf[1], flat + v->w_off[14], (size_t)F * F * 4, hipMemcpyHostToDevice));
+        NVQA_HIP(hipMemcpy(v->bf[1], flat + v->b_off[14], (size_t)F * 4, hipMemcpyHostToDevice));
+    }
+    v->have_weights = true;
+    return 0;
+}
+
+static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, const float *b, float *out)
+{
+    const int N = v->F;
+    int ks = 1;
+    while (ks < 16 && (size_t)((M + 63) / 64) * ((N + 63) / 64) * ks < 512 && K / (ks * 2) >= 256) ks *= 2;
+    int kslice = ((K + ks - 1) / ks + 31) / 32 * 32;
+    ks = (K + kslice - 1) / kslice;
+    GemmArgs g = {};
+    g.A = x; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kslice = kslice;
+    NVQA_HIP((launch_gemm<CfgFc, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
+    hipLaunchKernelGGL(k_fc_finish, dim3(((size_t)M * N + 255) / 256), dim3(256), 0, v->s, v->slabs, ks, M, N, b, out);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+// images: n x 3 x hw x hw, already preprocessed (BGR, mean-subtracted: loadim's output).
+extern "C" int nvqa_vgg16_fc7(nvqa_vgg *v, const float *images, int n, float *feats_out)
+{
+    if (!v || !images || !feats_out) { set_error("NULL argument"); return -1; }
+    if (!v->have_weights) { set_error("nvqa_vgg16_fc7 before nvqa_vgg16_set_weights"); return -1; }
+    if (n < 1 || n > v->max_batch) { set_error("n=%d outside 1..%d", n, v->max_batch); return -1; }
+    NVQA_HIP(hipSetDevice(v->device));
+    int H = v->hw, W = v->hw;
+    const size_t px = (size_t)n * H * W;
+    NVQA_HIP(hipMemcpyAsync(v->img, images, px * 3 * 4, hipMemcpyHostToDevice, v->s));
+    hipLaunchKernelGGL(k_nchw_to_nhwc4, dim3((px + 255) / 256), dim3(256), 0, v->s, v->img, n, H, W, reinterpret_cast<float4 *>(v->nhwc_in));
+    const float *cur = v->nhwc_in;
+    int which = 0;
+    for (int i = 0; i < 13; ++i) {
+        float *dst = v->act[which];
+        GemmArgs g = {};
+        g.A = cur; g.B = v->Wc[i]; g.ldb = 9 * v->cinp[i];
+        g.M = n * H * W; g.N = v->cout[i]; g.K = 9 * v->cinp[i]; g.kslice = g.K;
+        g.cH = H; g.cW = W; g.cC = v->cinp[i];
+        // output channel stride = padded C_out, so that the next layer reads float4 channels; the pad
+        // channels must be zero: they are written by nobody, so clear once when padding exists
+        const int ldc = v->coutp[i];
+        if (ldc != v->cout[i]) NVQA_HIP(hipMemsetAsync(dst, 0, (size_t)g.M * ldc * 4, v->s));
+        if (v->cout[i] > 64) {
+            NVQA_HIP((launch_gemm<CfgConv, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
+        } else {
+            NVQA_HIP((launch_gemm<CfgConv64, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
+        }
+        cur = dst; which ^= 1;
+        if (kPoolAfter[i]) {
+            float *pd = v->act[which];
+            const size_t total = (size_t)n * (H / 2) * (W / 2) * (ldc / 4);
+            hipLaunchKernelGGL(k_maxpool2_nhwc, dim3((total + 255) / 256), dim3(256), 0, v->s, reinterpret_cast<const float4 *>(cur), n, H, W, ldc / 4, reinterpret_cast<float4 *>(pd));
+            H /= 2; W /= 2;
+            cur = pd; which ^= 1;
+        }
+    }
+    NVQA_HIP(hipGetLastError());
+    const int c5p = (v->c5 + 3) / 4 * 4;
+    NVQA_TRY(fc_layer(v, cur, n, v->s5 * v->s5 * c5p, v->Wf[0], v->bf[0], v->fc6o)); // fc6 + ReLU (Dropout = identity)
+    NVQA_TRY(fc_layer(v, v->fc6o, n, v->F, v->Wf[1], v->bf[1], v->fc7o));              // fc7 + ReLU -> module 38
+    NVQA_HIP(hipMemcpyAsync(feats_out, v->fc7o, (size_t)n * v->F * 4, hipMemcpyDeviceToHost, v->s));
+    NVQA_HIP(hipStreamSynchronize(v->s));
+    return 0;
+}
+
+// rgb: n x 3 x H x W in [0,1] (image.load output) -> out: n x 3 x hw x hw preprocessed planes
+extern "C" int nvqa_vgg16_preprocess(nvqa_vgg *v, const float *rgb, int n, int H, int W, float *out)
+{
+    if (!v || !rgb || !out) { set_error("NULL argument"); return -1; }
+    if (n < 1 || H < 1 || W < 1) { set_error("bad image shape"); return -1; }
+    NVQA_HIP(hipSetDevice(v->device));
+    float *din = nullptr, *dout = nullptr;
+    const size_t nin = (size_t)n * 3 * H * W, nout = (size_t)n * 3 * v->hw * v->hw;
+    NVQA_HIP(hipMalloc((void **)&din, nin * 4));
+    NVQA_HIP(hipMalloc((void **)&dout, nout * 4));
+    NVQA_HIP(hipMemcpyAsync(din, rgb, nin * 4, hipMemcpyHostToDevice, v->s));
+    hipLaunchKernelGGL(k_vgg_preprocess, dim3((nout + 255) / 256), dim3(256), 0, v->s, din, n, H, W, v->hw, dout);
+    NVQA_HIP(hipGetLastError());
+    NVQA_HIP(hipMemcpyAsync(out, dout, nout * 4, hipMemcpyDeviceToHost, v->s));
+    NVQA_HIP(hipStreamSynchronize(v->s));
+    (void)hipFree(din); (void)hipFree(dout);
+    return 0;
+}

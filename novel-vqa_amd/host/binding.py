@@ -55,6 +55,13 @@ SYMBOLS = {
     "nvqa_step_indices": (ctypes.c_int, [_vp, _i64p, ctypes.POINTER(Dropout), _f32p]),
     "nvqa_comm_unique_id": (ctypes.c_int, [_vp]),
     "nvqa_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "nvqa_vgg16_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "nvqa_vgg16_destroy": (ctypes.c_int, [_vp]),
+    "nvqa_vgg16_weight_count": (ctypes.c_size_t, [_vp]),
+    "nvqa_vgg16_feature_dim": (ctypes.c_int, [_vp]),
+    "nvqa_vgg16_set_weights": (ctypes.c_int, [_vp, _f32p]),
+    "nvqa_vgg16_fc7": (ctypes.c_int, [_vp, _f32p, ctypes.c_int, _f32p]),
+    "nvqa_vgg16_preprocess": (ctypes.c_int, [_vp, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p]),
     "nvqa_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_profile_reset": (ctypes.c_int, [_vp]),
     "nvqa_profile_count": (ctypes.c_int, [_vp]),
@@ -228,3 +235,50 @@ class Context:
             out[self.lib.nvqa_profile_name(self._h, i).decode()] = {
                 "ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
         return out
+
+
+class Vgg16:
+    """VGG-16 fc7 extractor (001_prepro_img_vgg.lua): owns one nvqa_vgg."""
+
+    def __init__(self, device=0, width_div=1, input_hw=224, max_batch=16):
+        self.lib = load_library()
+        self._h = _vp()
+        self.hw = input_hw
+        self._check(self.lib.nvqa_vgg16_create(device, width_div, input_hw, max_batch, ctypes.byref(self._h)))
+        self.weight_count = int(self.lib.nvqa_vgg16_weight_count(self._h))
+        self.feature_dim = int(self.lib.nvqa_vgg16_feature_dim(self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NvqaError(f"libnvqa error {rc}: {self.lib.nvqa_last_error().decode()}")
+
+    def set_weights(self, flat):
+        w = np.ascontiguousarray(flat, np.float32)
+        assert w.size == self.weight_count
+        self._check(self.lib.nvqa_vgg16_set_weights(self._h, _f32(w)))
+
+    def fc7(self, images):
+        x = np.ascontiguousarray(images, np.float32)
+        n = x.shape[0]
+        assert x.shape[1:] == (3, self.hw, self.hw)
+        out = np.empty((n, self.feature_dim), np.float32)
+        self._check(self.lib.nvqa_vgg16_fc7(self._h, _f32(x), n, _f32(out)))
+        return out
+
+    def preprocess(self, rgb):
+        x = np.ascontiguousarray(rgb, np.float32)
+        n, _, H, W = x.shape
+        out = np.empty((n, 3, self.hw, self.hw), np.float32)
+        self._check(self.lib.nvqa_vgg16_preprocess(self._h, _f32(x), n, H, W, _f32(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            self.lib.nvqa_vgg16_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -35,6 +35,14 @@ int nvqa_dataset_load(nvqa_ctx *ctx, int64_t n_q, const int32_t *questions, cons
 int nvqa_step_indices(nvqa_ctx *ctx, const int64_t *qinds, const nvqa_dropout *dropout, float *loss_out);
 int nvqa_comm_unique_id(void *id_out);
 int nvqa_comm_init(nvqa_ctx *ctx, int rank, int world, const void *id);
+typedef struct nvqa_vgg nvqa_vgg;
+int nvqa_vgg16_create(int device, int width_div, int input_hw, int max_batch, nvqa_vgg **out);
+int nvqa_vgg16_destroy(nvqa_vgg *vgg);
+size_t nvqa_vgg16_weight_count(const nvqa_vgg *vgg);
+int nvqa_vgg16_feature_dim(const nvqa_vgg *vgg);
+int nvqa_vgg16_set_weights(nvqa_vgg *vgg, const float *flat);
+int nvqa_vgg16_fc7(nvqa_vgg *vgg, const float *images, int n, float *feats_out);
+int nvqa_vgg16_preprocess(nvqa_vgg *vgg, const float *rgb, int n, int H, int W, float *out);
 int nvqa_profile_enable(nvqa_ctx *ctx, int enable);
 int nvqa_profile_reset(nvqa_ctx *ctx);
 int nvqa_profile_count(const nvqa_ctx *ctx);

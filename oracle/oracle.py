@@ -35,10 +35,10 @@ def make_dims(arch=1, B=4, T=5, V=11, E=6, R=8, L=2, I=12, C=10, A=7):
 
 def build(force=False):
     """Compile both oracle libraries with the committed Makefile."""
-    libs = [os.path.join(_HERE, n) for n in ("liboracle_f32.so", "liboracle_f64.so")]
-    src = os.path.join(_HERE, "nvqa_oracle.c")
-    stale = force or any(
-        (not os.path.exists(l)) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs)
+    libs = [os.path.join(_HERE, n) for n in ("liboracle_f32.so", "liboracle_f64.so", "liboracle_vgg.so")]
+    srcs = [os.path.join(_HERE, n) for n in ("nvqa_oracle.c", "vgg_oracle.c")]
+    newest = max(os.path.getmtime(f) for f in srcs)
+    stale = force or any((not os.path.exists(l)) or os.path.getmtime(l) < newest for l in libs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
                               stdout=subprocess.DEVNULL)
@@ -191,3 +191,51 @@ def synth_batch(dims, seed=123, full_length=True, min_len=1):
     img /= np.sqrt((img * img).sum(1, keepdims=True))  # 002_train_baseline.lua:117-121
     labels = rng.integers(1, dims.A + 1, B).astype(np.int32)
     return tokens, lengths, img, labels
+
+
+# ----------------------------------------------------------------------------
+# VGG-16 fc7 (oracle/vgg_oracle.c)
+# ----------------------------------------------------------------------------
+class VggOracle:
+    def __init__(self, width_div=1, hw=224):
+        build()
+        self.lib = ctypes.CDLL(os.path.join(_HERE, "liboracle_vgg.so"))
+        self.lib.oracle_vgg16_weight_count.restype = ctypes.c_size_t
+        self.div, self.hw = width_div, hw
+        self.weight_count = int(self.lib.oracle_vgg16_weight_count(width_div, hw))
+        self.feature_dim = max(4, 4096 // width_div)
+
+    def synth_weights(self, seed=123):
+        """He-scaled random weights in the flat Caffe order (no caffemodel is available offline)."""
+        rng = np.random.default_rng(seed)
+        chans = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512]
+        parts, cin = [], 3
+        for c in chans:
+            co = max(1, c // self.div)
+            parts.append(rng.standard_normal(co * cin * 9).astype(np.float32) * np.sqrt(2.0 / (cin * 9)))
+            parts.append(rng.uniform(0.0, 0.1, co).astype(np.float32))
+            cin = co
+        S, F = self.hw // 32, self.feature_dim
+        for k in (cin * S * S, F):
+            parts.append(rng.standard_normal(F * k).astype(np.float32) * np.sqrt(2.0 / k))
+            parts.append(rng.uniform(0.0, 0.1, F).astype(np.float32))
+        w = np.concatenate(parts)
+        assert w.size == self.weight_count
+        return w
+
+    def fc7(self, flat, images):
+        x = np.ascontiguousarray(images, np.float32)
+        w = np.ascontiguousarray(flat, np.float32)
+        out = np.zeros((x.shape[0], self.feature_dim), np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        self.lib.oracle_vgg16_fc7(self.div, self.hw, w.ctypes.data_as(fp), x.ctypes.data_as(fp), x.shape[0],
+                                  out.ctypes.data_as(fp))
+        return out
+
+    def preprocess(self, rgb, S):
+        x = np.ascontiguousarray(rgb, np.float32)
+        n, _, H, W = x.shape
+        out = np.zeros((n, 3, S, S), np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        self.lib.oracle_vgg16_preprocess(x.ctypes.data_as(fp), n, H, W, S, out.ctypes.data_as(fp))
+        return out

@@ -1,0 +1,135 @@
+/*
+ * vgg_oracle.c -- CPU restatement of the VGG-16 fc7 extractor.  TEST INFRASTRUCTURE ONLY
+ * (see nvqa_oracle.c).  PARITY UNPINNED: the Caffe model and Torch7 are not available; this is
+ * the public 16-layer VGG definition (13 conv3x3 pad 1 + ReLU, 5 max-pool 2x2/2, fc6+ReLU,
+ * fc7+ReLU) that 002_train_vqa_arch1/001_prepro_img_vgg.lua:36-37,109-110 loads and taps at
+ * module 38 (post-ReLU fc7; Dropout is the identity in evaluate mode), plus loadim (:47-71).
+ * Direct convolution in NCHW with Caffe OIHW weights -- deliberately not the implicit-GEMM /
+ * NHWC formulation of the HIP path.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const int kCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+static const int kPool[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
+
+static int imax(int a, int b) { return a > b ? a : b; }
+
+size_t oracle_vgg16_weight_count(int width_div, int hw)
+{
+    size_t off = 0;
+    int cin = 3;
+    for (int i = 0; i < 13; ++i) {
+        const int co = imax(1, kCout[i] / width_div);
+        off += (size_t)co * cin * 9 + co;
+        cin = co;
+    }
+    const int S = hw / 32, F = imax(4, 4096 / width_div);
+    off += (size_t)F * cin * S * S + F;
+    off += (size_t)F * F + F;
+    return off;
+}
+
+/* images n x 3 x hw x hw (preprocessed) -> out n x F */
+int oracle_vgg16_fc7(int width_div, int hw, const float *flat, const float *images, int n, float *out)
+{
+    int cin = 3, H = hw, W = hw;
+    const float *p = flat;
+    float *cur = (float *)malloc(sizeof(float) * (size_t)n * 3 * hw * hw);
+    memcpy(cur, images, sizeof(float) * (size_t)n * 3 * hw * hw);
+    for (int i = 0; i < 13; ++i) {
+        const int co = imax(1, kCout[i] / width_div);
+        const float *Wt = p, *b = p + (size_t)co * cin * 9;
+        p = b + co;
+        float *nxt = (float *)malloc(sizeof(float) * (size_t)n * co * H * W);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int im = 0; im < n; ++im)
+            for (int o = 0; o < co; ++o) {
+                float *dst = nxt + ((size_t)im * co + o) * H * W;
+                for (int q = 0; q < H * W; ++q) dst[q] = b[o];
+                for (int c = 0; c < cin; ++c) {
+                    const float *src = cur + ((size_t)im * cin + c) * H * W;
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float w = Wt[(((size_t)o * cin + c) * 3 + ky) * 3 + kx];
+                            for (int y = 0; y < H; ++y) {
+                                const int iy = y + ky - 1;
+                                if (iy < 0 || iy >= H) continue;
+                                const int x0 = kx == 0 ? 1 : 0, x1 = kx == 2 ? W - 1 : W;
+                                for (int x = x0; x < x1; ++x) dst[y * W + x] += w * src[iy * W + x + kx - 1];
+                            }
+                        }
+                }
+                for (int q = 0; q < H * W; ++q) dst[q] = dst[q] > 0 ? dst[q] : 0; /* ReLU */
+            }
+        free(cur);
+        cur = nxt;
+        cin = co;
+        if (kPool[i]) {
+            const int Ho = H / 2, Wo = W / 2;
+            float *pl = (float *)malloc(sizeof(float) * (size_t)n * cin * Ho * Wo);
+            for (size_t ic = 0; ic < (size_t)n * cin; ++ic)
+                for (int y = 0; y < Ho; ++y)
+                    for (int x = 0; x < Wo; ++x) {
+                        const float *s = cur + ic * H * W + (size_t)(2 * y) * W + 2 * x;
+                        float m = s[0];
+                        if (s[1] > m) m = s[1];
+                        if (s[W] > m) m = s[W];
+                        if (s[W + 1] > m) m = s[W + 1];
+                        pl[ic * Ho * Wo + (size_t)y * Wo + x] = m;
+                    }
+            free(cur);
+            cur = pl;
+            H = Ho; W = Wo;
+        }
+    }
+    const int F = imax(4, 4096 / width_div), K6 = cin * H * W;
+    float *f6 = (float *)malloc(sizeof(float) * (size_t)n * F);
+    const float *W6 = p, *b6 = p + (size_t)F * K6;
+    p = b6 + F;
+    const float *W7 = p, *b7 = p + (size_t)F * F;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int im = 0; im < n; ++im)
+        for (int f = 0; f < F; ++f) {
+            double acc = b6[f];
+            const float *x = cur + (size_t)im * K6, *w = W6 + (size_t)f * K6; /* CHW flatten (nn.View) */
+            for (int k = 0; k < K6; ++k) acc += (double)x[k] * w[k];
+            f6[(size_t)im * F + f] = acc > 0 ? (float)acc : 0.f;
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int im = 0; im < n; ++im)
+        for (int f = 0; f < F; ++f) {
+            double acc = b7[f];
+            const float *x = f6 + (size_t)im * F, *w = W7 + (size_t)f * F;
+            for (int k = 0; k < F; ++k) acc += (double)x[k] * w[k];
+            out[(size_t)im * F + f] = acc > 0 ? (float)acc : 0.f;
+        }
+    free(cur);
+    free(f6);
+    return 0;
+}
+
+/* loadim (001_prepro_img_vgg.lua:47-71) minus the file decode: rgb n x 3 x H x W in [0,1] ->
+ * n x 3 x S x S BGR planes, x255, mean-subtracted.  Align-corners bilinear (Torch's image.scale
+ * interpolation is not pinned by the reference). */
+void oracle_vgg16_preprocess(const float *rgb, int n, int H, int W, int S, float *out)
+{
+    static const float mean[3] = {103.939f, 116.779f, 123.68f};
+    for (int im = 0; im < n; ++im)
+        for (int c = 0; c < 3; ++c)
+            for (int y = 0; y < S; ++y)
+                for (int x = 0; x < S; ++x) {
+                    const float fy = S > 1 ? (float)y * (float)(H - 1) / (float)(S - 1) : 0.f;
+                    const float fx = S > 1 ? (float)x * (float)(W - 1) / (float)(S - 1) : 0.f;
+                    int y0 = (int)fy, x0 = (int)fx;
+                    if (y0 > H - 1) y0 = H - 1;
+                    if (x0 > W - 1) x0 = W - 1;
+                    const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+                    const float wy = fy - (float)y0, wx = fx - (float)x0;
+                    const float *p = rgb + ((size_t)im * 3 + (2 - c)) * H * W;
+                    const float v = (1.f - wy) * ((1.f - wx) * p[(size_t)y0 * W + x0] + wx * p[(size_t)y0 * W + x1]) +
+                                    wy * ((1.f - wx) * p[(size_t)y1 * W + x0] + wx * p[(size_t)y1 * W + x1]);
+                    out[(((size_t)im * 3 + c) * S + y) * S + x] = v * 255.0f - mean[c];
+                }
+}
