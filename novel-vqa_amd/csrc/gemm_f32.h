@@ -82,9 +82,11 @@ __device__ __forceinline__ f32x4 mfma<16>(float a, float b, f32x4 c)
 
 // Tile configuration
 // DBG (ablation builds of tools/kbench only): 1 = no global loads, 2 = no MFMA loop, 4 = no epilogue
-template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0> struct Cfg {
+// DMA = 1: tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write);
+// two LDS buffers, the next tile's DMA is in flight while the current one is multiplied.
+template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0, int DMA_ = 0> struct Cfg {
     static constexpr int MF = MF_, BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_, PF = PF_;
-    static constexpr int DBG = DBG_;
+    static constexpr int DBG = DBG_, DMA = DMA_;
 };
 
 // Epilogue concept:
@@ -126,8 +128,12 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     // K-contiguous operands: LDS image [rows][BK], chunk-swizzled, read with ds_read_b128.
     // M/N-contiguous operands: LDS image [BK][rows + 4], read with ds_read_b32 (the 4 floats of a
     // q step sit 4 rows apart for the KI lane groups: (4*LD) % 32 == 16 keeps MF=16 conflict-free).
-    constexpr int LDA = AMODE != A_MC ? BK : BM + 4;
-    constexpr int LDB = BMODE == B_KC ? BK : BN + 4;
+    // (an LDS-DMA piece is 1 KiB of consecutive LDS: k-major images cannot be padded then, which is
+    // conflict-free only for the 32-wide MFMA operand read)
+    constexpr bool DMA = C::DMA != 0;
+    static_assert(!DMA || MF == 32 || (AMODE != A_MC && BMODE == B_KC), "DMA with k-major operands needs MF = 32");
+    constexpr int LDA = AMODE != A_MC ? BK : (DMA ? BM : BM + 4);
+    constexpr int LDB = BMODE == B_KC ? BK : (DMA ? BN : BN + 4);
     constexpr int A_FL = AMODE != A_MC ? BM * BK : BK * LDA;
     constexpr int B_FL = BMODE == B_KC ? BN * BK : BK * LDB;
     constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
@@ -135,7 +141,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     constexpr int BUF = A_FL + B_FL; // floats per LDS buffer (A image then B image)
     constexpr int ACCN = NTM * NTN * NREG;
     constexpr int RED = WK > 1 ? WK * WM * WN * ACCN * 64 : 0;
-    constexpr int SMEM = (PF * BUF > RED ? PF * BUF : RED);
+    constexpr int NBUF = DMA ? 2 : PF;
+    constexpr int SMEM = (NBUF * BUF > RED ? NBUF * BUF : RED);
 
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -198,12 +205,67 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     const int nk2 = SEG > 0 && active ? (g.K2 + BK - 1) / BK : 0;
     const int nk = nk1 + nk2;
 
+    // ---- per-thread invariants of the tile loop (hoisted: the step kernels spend as many issue
+    // cycles on address arithmetic as on MFMAs otherwise) ---------------------------------------
+    // global source pointer of each staged float4 at tile 0 of a segment (nullptr: row/col out of
+    // range -> zeros), its k offset inside the tile, and its LDS destination offset
+    constexpr int NSEG = SEG > 0 ? 2 : 1;
+    const float *pA[NSEG][NA], *pB[NSEG][NB];
+    int kA[NA], kB[NB], sA[NA], sB[NB];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int f = tid + j * NT;
+        const bool inb = A_F4 % NT == 0 || f < A_F4;
+        if (AMODE != A_MC) {
+            const int row = f / (BK / 4), kq = f % (BK / 4), m = m0 + row;
+            kA[j] = 4 * kq;
+            sA[j] = row * BK + 4 * swz_chunk<BK>(row, kq);
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg)
+                pA[sg][j] = (inb && m < mlim && AMODE == A_KC) ? (sg ? g.A2 + (size_t)m * g.lda2 : g.A + (size_t)m * g.lda) + 4 * kq : nullptr;
+        } else {
+            const int kr = f / (BM / 4), mq = f % (BM / 4), m = m0 + 4 * mq;
+            kA[j] = kr;
+            sA[j] = kr * LDA + 4 * mq;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg)
+                pA[sg][j] = (inb && m < g.M) ? (sg ? g.A2 + (size_t)kr * g.lda2 : g.A + (size_t)kr * g.lda) + m : nullptr;
+        }
+        if (!inb) sA[j] = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int f = tid + j * NT;
+        const bool inb = B_F4 % NT == 0 || f < B_F4;
+        if (BMODE == B_KC) {
+            const int row = f / (BK / 4), kq = f % (BK / 4);
+            int n;
+            bool ok;
+            if (GATES) {
+                const int u = n0 + row % BU;
+                n = (row / BU) * g.R + u;
+                ok = u < g.N;
+            } else {
+                n = n0 + row;
+                ok = n < g.N;
+            }
+            kB[j] = 4 * kq;
+            sB[j] = row * BK + 4 * swz_chunk<BK>(row, kq);
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg)
+                pB[sg][j] = (inb && ok) ? (sg ? g.B2 + (size_t)n * g.ldb2 : g.B + (size_t)n * g.ldb) + 4 * kq : nullptr;
+        } else {
+            const int kr = f / (BN / 4), nq = f % (BN / 4), n = n0 + 4 * nq;
+            kB[j] = kr;
+            sB[j] = kr * LDB + 4 * nq;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg)
+                pB[sg][j] = (inb && n < g.N) ? (sg ? g.B2 + (size_t)kr * g.ldb2 : g.B + (size_t)kr * g.ldb) + n : nullptr;
+        }
+        if (!inb) sB[j] = -1;
+    }
+
     auto load_tiles = [&](int kt, float4(&ra)[NA], float4(&rb)[NB]) {
-        const bool s2 = SEG > 0 && kt >= nk1;
-        const float *gA = s2 ? g.A2 : g.A, *gB = s2 ? g.B2 : g.B;
-        const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
-        const int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
-        const int kend = s2 ? g.K2 : min(g.K, kbeg + g.kslice);
         if constexpr (C::DBG & 1) {
 #pragma unroll
             for (int j = 0; j < NA; ++j) ra[j] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -211,128 +273,174 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
             for (int j = 0; j < NB; ++j) rb[j] = make_float4(1.f, 1.f, 1.f, 1.f);
             return;
         }
+        const bool s2 = SEG > 0 && kt >= nk1;
+        const int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
+        const int kend = s2 ? g.K2 : min(g.K, kbeg + g.kslice);
+        const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int f = tid + j * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (A_F4 % NT == 0 || f < A_F4) {
-                if (AMODE == A_KC) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    const int m = m0 + row, k = k0 + 4 * kq;
-                    if (m < mlim && k < kend) v = *reinterpret_cast<const float4 *>(gA + (size_t)m * glda + k);
-                } else if (AMODE == A_IM2COL) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    const int m = m0 + row, k = k0 + 4 * kq;
-                    if (m < mlim && k < kend) {
-                        const int hw = g.cH * g.cW;
-                        const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
-                        const int tap = k / g.cC, ci = k - tap * g.cC, ky = tap / 3, kx = tap - ky * 3;
-                        const int iy = y + ky - 1, ix = x + kx - 1;
-                        if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
-                            v = *reinterpret_cast<const float4 *>(gA + (((size_t)n * g.cH + iy) * g.cW + ix) * g.cC + ci);
-                    }
-                } else {
-                    const int kr = f / (BM / 4), mq = f % (BM / 4);
-                    const int k = k0 + kr, m = m0 + 4 * mq;
-                    if (k < kend && m < g.M) v = *reinterpret_cast<const float4 *>(gA + (size_t)k * glda + m);
+            if constexpr (AMODE == A_IM2COL) {
+                const int f = tid + j * NT;
+                const int row = f / (BK / 4), m = m0 + row, k = k0 + kA[j];
+                if ((A_F4 % NT == 0 || f < A_F4) && m < mlim && k < kend) {
+                    const int hw = g.cH * g.cW;
+                    const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
+                    const int tap = k / g.cC, ci = k - tap * g.cC, ky = tap / 3, kx = tap - ky * 3;
+                    const int iy = y + ky - 1, ix = x + kx - 1;
+                    if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
+                        v = *reinterpret_cast<const float4 *>(g.A + (((size_t)n * g.cH + iy) * g.cW + ix) * g.cC + ci);
                 }
+            } else {
+                const float *p = SEG > 0 && s2 ? pA[NSEG - 1][j] : pA[0][j];
+                if (p && k0 + kA[j] < kend)
+                    v = *reinterpret_cast<const float4 *>(AMODE == A_KC ? p + k0 : p + (size_t)k0 * glda);
             }
             ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int f = tid + j * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (B_F4 % NT == 0 || f < B_F4) {
-                if (BMODE == B_KC) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    const int k = k0 + 4 * kq;
-                    int n;
-                    bool ok;
-                    if (GATES) {
-                        const int u = n0 + row % BU;
-                        n = (row / BU) * g.R + u;
-                        ok = u < g.N;
-                    } else {
-                        n = n0 + row;
-                        ok = n < g.N;
-                    }
-                    if (ok && k < kend) v = *reinterpret_cast<const float4 *>(gB + (size_t)n * gldb + k);
-                } else {
-                    const int kr = f / (BN / 4), nq = f % (BN / 4);
-                    const int k = k0 + kr, n = n0 + 4 * nq;
-                    if (k < kend && n < g.N) v = *reinterpret_cast<const float4 *>(gB + (size_t)k * gldb + n);
-                }
-            }
+            const float *p = SEG > 0 && s2 ? pB[NSEG - 1][j] : pB[0][j];
+            if (p && k0 + kB[j] < kend)
+                v = *reinterpret_cast<const float4 *>(BMODE == B_KC ? p + k0 : p + (size_t)k0 * gldb);
             rb[j] = v;
         }
     };
     auto store_tiles = [&](int buf, const float4(&ra)[NA], const float4(&rb)[NB]) {
         float *As = smem + buf * BUF, *Bs = As + A_FL;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int f = tid + j * NT;
-            if (A_F4 % NT == 0 || f < A_F4) {
-                if (AMODE != A_MC) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    *reinterpret_cast<float4 *>(&As[row * BK + 4 * swz_chunk<BK>(row, kq)]) = ra[j];
-                } else {
-                    const int kr = f / (BM / 4), mq = f % (BM / 4);
-                    *reinterpret_cast<float4 *>(&As[kr * LDA + 4 * mq]) = ra[j];
-                }
+        for (int j = 0; j < NA; ++j)
+            if (A_F4 % NT == 0 || sA[j] >= 0) *reinterpret_cast<float4 *>(&As[sA[j]]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (B_F4 % NT == 0 || sB[j] >= 0) *reinterpret_cast<float4 *>(&Bs[sB[j]]) = rb[j];
+    };
+
+    // MFMA operand fragments: lane (li, lh) of q step q reads the 4 consecutive k of chunk KI*q + lh
+    // (K-contiguous images, one ds_read_b128) or k = QK*q + 4*lh + {0..3} (k-major images, 4 ds_read_b32)
+    int fA[NTM], xA[NTM], fB[NTN], xB[NTN];
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+        const int row = wm * TM + t * MF + li;
+        fA[t] = AMODE != A_MC ? row * BK : 4 * lh * LDA + row;
+        xA[t] = BK >= 64 ? (row & 15) : ((row >> 1) & 7);
+    }
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+        const int col = GATES ? t * BU + wn * MF + li : wn * TN + t * MF + li;
+        fB[t] = BMODE == B_KC ? col * BK : 4 * lh * LDB + col;
+        xB[t] = BK >= 64 ? (col & 15) : ((col >> 1) & 7);
+    }
+    auto read_frags = [&](const float *As, const float *Bs, int q, float4(&a)[NTM], float4(&b)[NTN]) {
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) {
+            if constexpr (AMODE != A_MC) {
+                a[t] = *reinterpret_cast<const float4 *>(&As[fA[t] + 4 * ((KI * q + lh) ^ xA[t])]);
+            } else {
+                const float *p = &As[fA[t] + QK * q * LDA];
+                a[t] = make_float4(p[0], p[LDA], p[2 * LDA], p[3 * LDA]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int f = tid + j * NT;
-            if (B_F4 % NT == 0 || f < B_F4) {
-                if (BMODE == B_KC) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    *reinterpret_cast<float4 *>(&Bs[row * BK + 4 * swz_chunk<BK>(row, kq)]) = rb[j];
-                } else {
-                    const int kr = f / (BN / 4), nq = f % (BN / 4);
-                    *reinterpret_cast<float4 *>(&Bs[kr * LDB + 4 * nq]) = rb[j];
-                }
+        for (int t = 0; t < NTN; ++t) {
+            if constexpr (BMODE == B_KC) {
+                b[t] = *reinterpret_cast<const float4 *>(&Bs[fB[t] + 4 * ((KI * q + lh) ^ xB[t])]);
+            } else {
+                const float *p = &Bs[fB[t] + QK * q * LDB];
+                b[t] = make_float4(p[0], p[LDB], p[2 * LDB], p[3 * LDB]);
             }
         }
     };
     auto compute = [&](int buf, typename AccT<MF>::type(&acc)[NTM][NTN]) {
         if constexpr (C::DBG & 2) return;
         const float *As = smem + buf * BUF, *Bs = As + A_FL;
+        // software-pipelined: the fragments of q step qq+1 are requested before the MFMAs of qq
+        float4 a[2][NTM], b[2][NTN];
+        read_frags(As, Bs, wk * QPW, a[0], b[0]);
 #pragma unroll
         for (int qq = 0; qq < QPW; ++qq) {
-            const int q = wk * QPW + qq;
-            float4 a[NTM], b[NTN];
-#pragma unroll
-            for (int t = 0; t < NTM; ++t) {
-                const int row = wm * TM + t * MF + li;
-                if constexpr (AMODE != A_MC) {
-                    a[t] = *reinterpret_cast<const float4 *>(&As[row * BK + 4 * swz_chunk<BK>(row, KI * q + lh)]);
-                } else {
-                    const float *p = &As[(QK * q + 4 * lh) * LDA + row];
-                    a[t] = make_float4(p[0], p[LDA], p[2 * LDA], p[3 * LDA]);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NTN; ++t) {
-                const int col = GATES ? t * BU + wn * MF + li : wn * TN + t * MF + li;
-                if constexpr (BMODE == B_KC) {
-                    b[t] = *reinterpret_cast<const float4 *>(&Bs[col * BK + 4 * swz_chunk<BK>(col, KI * q + lh)]);
-                } else {
-                    const float *p = &Bs[(QK * q + 4 * lh) * LDB + col];
-                    b[t] = make_float4(p[0], p[LDB], p[2 * LDB], p[3 * LDB]);
-                }
-            }
+            if (qq + 1 < QPW) read_frags(As, Bs, wk * QPW + qq + 1, a[(qq + 1) & 1], b[(qq + 1) & 1]);
 #pragma unroll
             for (int w = 0; w < 4; ++w)
 #pragma unroll
                 for (int ta = 0; ta < NTM; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < NTN; ++tb) {
-                        const float av = w == 0 ? a[ta].x : w == 1 ? a[ta].y : w == 2 ? a[ta].z : a[ta].w;
-                        const float bv = w == 0 ? b[tb].x : w == 1 ? b[tb].y : w == 2 ? b[tb].z : b[tb].w;
+                        const float4 &av4 = a[qq & 1][ta], &bv4 = b[qq & 1][tb];
+                        const float av = w == 0 ? av4.x : w == 1 ? av4.y : w == 2 ? av4.z : av4.w;
+                        const float bv = w == 0 ? bv4.x : w == 1 ? bv4.y : w == 2 ? bv4.z : bv4.w;
                         acc[ta][tb] = mfma<MF>(av, bv, acc[ta][tb]);
                     }
+        }
+    };
+
+    // LDS-DMA: lane l of wave-instruction i delivers the 16-byte chunk P = i*64 + l of the LDS image;
+    // the (inverse-)swizzle goes on the per-lane SOURCE address (cdna_hip_programming.md rule 21).
+    // Out-of-range chunks are zero-filled with an ordinary LDS store instead.
+    auto dma_tiles = [&](int kt, int buf) {
+        constexpr int NW = NT / 64;
+        const bool s2 = SEG > 0 && kt >= nk1;
+        const float *gA = s2 ? g.A2 : g.A, *gB = s2 ? g.B2 : g.B;
+        const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
+        const int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
+        const int kend = s2 ? g.K2 : min(g.K, kbeg + g.kslice);
+        float *As = smem + buf * BUF, *Bs = As + A_FL;
+        typedef __attribute__((address_space(3))) void *lds_t;
+        typedef const __attribute__((address_space(1))) void *glb_t;
+#pragma unroll
+        for (int i = 0; i < (A_F4 + NT - 1) / NT; ++i) {
+            const int piece = i * NW + wave; // wave-uniform
+            const int P = piece * 64 + lane;
+            if (A_F4 % NT != 0 && piece * 64 >= A_F4) break;
+            const float *src = nullptr;
+            if (AMODE != A_MC) {
+                const int row = P / (BK / 4), kq = swz_chunk<BK>(row, P % (BK / 4));
+                const int m = m0 + row, k = k0 + 4 * kq;
+                if (AMODE == A_KC) {
+                    if (m < mlim && k < kend) src = gA + (size_t)m * glda + k;
+                } else if (m < mlim && k < kend) {
+                    const int hw = g.cH * g.cW;
+                    const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
+                    const int tap = k / g.cC, ci = k - tap * g.cC, ky = tap / 3, kx = tap - ky * 3;
+                    const int iy = y + ky - 1, ix = x + kx - 1;
+                    if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) src = gA + (((size_t)n * g.cH + iy) * g.cW + ix) * g.cC + ci;
+                }
+            } else {
+                const int kr = P / (BM / 4), mq = P % (BM / 4);
+                const int k = k0 + kr, m = m0 + 4 * mq;
+                if (k < kend && m < g.M) src = gA + (size_t)k * glda + m;
+            }
+            if (src) __builtin_amdgcn_global_load_lds((glb_t)src, (lds_t)(As + piece * 256), 16, 0, 0);
+            else *reinterpret_cast<float4 *>(As + (size_t)P * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < (B_F4 + NT - 1) / NT; ++i) {
+            const int piece = i * NW + wave;
+            const int P = piece * 64 + lane;
+            if (B_F4 % NT != 0 && piece * 64 >= B_F4) break;
+            const float *src = nullptr;
+            if (BMODE == B_KC) {
+                const int row = P / (BK / 4), kq = swz_chunk<BK>(row, P % (BK / 4));
+                const int k = k0 + 4 * kq;
+                int n;
+                bool ok;
+                if (GATES) {
+                    const int u = n0 + row % BU;
+                    n = (row / BU) * g.R + u;
+                    ok = u < g.N;
+                } else {
+                    n = n0 + row;
+                    ok = n < g.N;
+                }
+                if (ok && k < kend) src = gB + (size_t)n * gldb + k;
+            } else {
+                const int kr = P / (BN / 4), nq = P % (BN / 4);
+                const int k = k0 + kr, n = n0 + 4 * nq;
+                if (k < kend && n < g.N) src = gB + (size_t)k * gldb + n;
+            }
+            if (src) __builtin_amdgcn_global_load_lds((glb_t)src, (lds_t)(Bs + piece * 256), 16, 0, 0);
+            else *reinterpret_cast<float4 *>(Bs + (size_t)P * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -343,7 +451,15 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         compute(buf, acc);
     };
     if (nk > 0) {
-        if constexpr (PF == 1) {
+        if constexpr (DMA) {
+            dma_tiles(0, 0);
+            __syncthreads(); // hipcc drains vmcnt before the barrier: the DMA has landed
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) dma_tiles(kt + 1, (kt + 1) & 1);
+                compute_tile(kt & 1, kt);
+                __syncthreads();
+            }
+        } else if constexpr (PF == 1) {
             float4 ra[NA], rb[NB];
             load_tiles(0, ra, rb);
             store_tiles(0, ra, rb);
@@ -459,23 +575,24 @@ __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_kernel(Ge
 // Several independent problems of the same shape class in ONE launch (blockIdx.z = problem):
 // the LSTM steps of different layers on one wavefront diagonal.  More workgroups per launch
 // (two per CU overlap each other's prologue / epilogue) and one kernel boundary per diagonal.
-#define NVQA_MULTI_MAX 4
+#define NVQA_MULTI_MAX 8
 template <class Epi> struct MultiArgs {
     GemmArgs g[NVQA_MULTI_MAX];
     Epi e[NVQA_MULTI_MAX];
+    int zsplit = 1; // K slices per problem (cross-CU split-K: the epilogue sees z and writes a slab)
 };
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
 __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_multi_kernel(MultiArgs<Epi> a)
 {
-    const int p = blockIdx.z;
-    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(a.g[p], a.e[p], blockIdx.x, blockIdx.y, 0);
+    const int p = blockIdx.z / a.zsplit, z = blockIdx.z % a.zsplit;
+    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(a.g[p], a.e[p], blockIdx.x, blockIdx.y, z);
 }
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
 inline hipError_t launch_gemm_multi(hipStream_t s, const MultiArgs<Epi> &a, int nprob)
 {
     const GemmArgs &g = a.g[0]; // all problems share M and N (grid shape)
     dim3 grid(GATES ? (g.N + C::BN / 4 - 1) / (C::BN / 4) : (g.N + C::BN - 1) / C::BN,
-              (g.M + C::BM - 1) / C::BM, nprob);
+              (g.M + C::BM - 1) / C::BM, nprob * a.zsplit);
     hipLaunchKernelGGL((gemm_f32_multi_kernel<C, AMODE, BMODE, GATES, Epi, SEG>), grid,
                        dim3(64 * C::WM * C::WN * C::WK), 0, s, a);
     return hipGetLastError();

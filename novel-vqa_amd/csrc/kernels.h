@@ -4,6 +4,7 @@
 // where the row width allows, no atomics on floats (results are bit-reproducible).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/nvqa_layout.h"
 #include "epilogues.h"
 
 namespace nvqa {
@@ -265,16 +266,20 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
                           int NP /*T*B*/, int B, int T, int V, int E, Drop dr, float *dWeT /*[V][E]*/,
                           int plain /* 1: nn.LookupTable (arch2): the row gradient is dX itself */)
 {
+    // A workgroup owns 16 vocabulary rows; its waves scan consecutive quarters of the packed token
+    // list into private LDS accumulators, which are then summed in wave order: a fixed summation
+    // order (ascending packed position within a wave, waves in order), so still bit-reproducible.
     extern __shared__ float acc[]; // [waves][16][E]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
-    const int v0 = (blockIdx.x * waves + wave) * NVQA_EB_ROWS;
-    if (v0 >= V) return;
+    const int v0 = blockIdx.x * NVQA_EB_ROWS;
     float *my = acc + (size_t)wave * NVQA_EB_ROWS * E;
     for (int i = lane; i < NVQA_EB_ROWS * E; i += 64) my[i] = 0.f;
-    for (int k0 = 0; k0 < NP; k0 += 64) {
+    const int per = ((NP + waves - 1) / waves + 63) / 64 * 64;
+    const int kbeg = wave * per, kend = min(NP, kbeg + per);
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
         const int k = k0 + lane;
-        const int w = k < NP ? ptok[k] : -1;
+        const int w = k < kend ? ptok[k] : -1;
         unsigned long long hit = __ballot(w >= v0 && w < v0 + NVQA_EB_ROWS);
         while (hit) {
             const int src = __ffsll((long long)hit) - 1;
@@ -293,8 +298,13 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
             }
         }
     }
+    __syncthreads();
     const int nr = min(NVQA_EB_ROWS, V - v0);
-    for (int i = lane; i < nr * E; i += 64) dWeT[(size_t)v0 * E + i] = my[i];
+    for (int i = threadIdx.x; i < nr * E; i += blockDim.x) {
+        float s = 0.f;
+        for (int wv = 0; wv < waves; ++wv) s += acc[(size_t)wv * NVQA_EB_ROWS * E + i];
+        dWeT[(size_t)v0 * E + i] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -362,6 +372,38 @@ __global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int
     const float *src = Htop + ((size_t)tinfo[0] * B + b) * R;
     for (int j = threadIdx.x; j < R; j += blockDim.x)
         hd[(size_t)b * R + j] = dr.scale(NVQA_SITE_Q, (uint64_t)b * R + j) * src[j];
+}
+
+// ---------------------------------------------------------------------------------
+// BPTT level finisher.  The recurrent products of one wavefront level are computed as split-K
+// GEMMs with 64x64 tiles into partial slabs (a 512x512 output is too small to fill 256 CUs with
+// tiles that have a useful arithmetic intensity otherwise: the fused 32x32-tile kernel was bound
+// by the ~70 GB/s each CU can pull from L2); this kernel sums the slabs in order and applies the
+// fused cell backward of EpiLstmBwd.  blockIdx.y = problem (layer).
+// ---------------------------------------------------------------------------------
+struct BwdFinish {
+    EpiLstmBwd e[NVQA_MAX_LAYERS];
+    const float *srec[NVQA_MAX_LAYERS]; // [Z][B][R] partials of dG_{s+1} W_h2h, or NULL
+    const float *sup[NVQA_MAX_LAYERS];  // [Z][B][R] partials of dG^{l+1}_s W_i2h^{l+1}, or NULL
+    int Z, B, R;
+};
+__global__ void k_lstm_bwd_finish(BwdFinish a)
+{
+    const int p = blockIdx.y;
+    const size_t n = (size_t)a.B * a.R;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = (int)(i / a.R), u = (int)(i % a.R);
+    const EpiLstmBwd &e = a.e[p];
+    const EpiLstmBwd::Pre q = e.preload(m, u);
+    float v = 0.f, v2 = 0.f;
+    if (m < q.nr) {
+        if (a.srec[p])
+            for (int z = 0; z < a.Z; ++z) v += a.srec[p][(size_t)z * n + i];
+        if (a.sup[p])
+            for (int z = 0; z < a.Z; ++z) v2 += a.sup[p][(size_t)z * n + i];
+    }
+    e(0, m, u, v, v2, q);
 }
 
 // ---------------------------------------------------------------------------------

@@ -90,7 +90,7 @@ static void prof_collect(nvqa_ctx *c)
 //                 MF   BM   BN   BK  WM WN WK PF
 typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgMed;
-#define NVQA_WG_CHUNK 2 // LSTM steps per weight-gradient chunk
+#define NVQA_BWD_Z 4 // K slices of the BPTT level products
 typedef Cfg<16, 32, 128, 32, 2, 2, 2, 2> CfgLstmFwd; // 8 waves: 2 K-groups x (2x2) tiles of 16 rows x 16 units x 4 gates
 typedef Cfg<16, 32, 32, 128, 2, 2, 4, 2> CfgLstmBwd; // 16 waves: 4 K-groups x (2x2) tiles of 16x16
 
@@ -247,6 +247,7 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
     NVQA_TRY(dalloc(&c->slabs2, c->slab_floats));
+    NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * B * R));
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
     NVQA_HIP(hipStreamSynchronize(c->s));
@@ -262,7 +263,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     prof_collect(c);
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
-                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->slabs2,
+                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->slabs2, c->chain_slabs,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -444,7 +445,10 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
         const int in = d.E;
         ProfScope ps(c, PF_GEMM_I2H, 2.0 * TB * 4 * R * in, ((double)TB * (in + 4 * R) + 4.0 * R * in) * 4);
         GemmArgs g = mkargs(c->X0, in, c->P + c->lo.w_i2h[0], in, TB, 4 * R, in);
-        NVQA_TRY((gemm_big<A_KC, B_KC>(c, g, EpiBias2{c->Gt[0], 4 * R, c->P + c->lo.b_i2h[0], c->P + c->lo.b_h2h[0]})));
+        // K-contiguous x K-contiguous: the 128x64 tile with the 2-deep pipeline measured 112 TF vs 101 TF
+        // for 128x128 (tools/kbench3)
+        NVQA_HIP((launch_gemm<Cfg<32, 128, 64, 32, 2, 2, 1, 2>, A_KC, B_KC, false, EpiBias2>(
+            c->s, g, EpiBias2{c->Gt[0], 4 * R, c->P + c->lo.b_i2h[0], c->P + c->lo.b_h2h[0]})));
     }
     // Wavefront over (layer, step): layer l at step t needs layer l at t-1 and layer l-1 at t, so
     // diagonal dg = t + l holds up to L independent steps; they go out as ONE launch.
@@ -499,15 +503,20 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
     NVQA_HIP(hipStreamWaitEvent(c->sb, c->evHead, 0));
     NVQA_HIP(hipStreamWaitEvent(c->sb2, c->evHead, 0));
     for (int dg = 0; dg < TS + L - 1; ++dg) {
-        // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j)
-        MultiArgs<EpiLstmBwd> ma;
-        int np = 0;
+        // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j).
+        // Products of the level: dG_{s+1} W_h2h (none at the last step) and, below the top layer,
+        // dG^{l+1}_s W_i2h^{l+1}; all are [B x 4R] x [4R x R] -> split-K GEMMs into slabs in ONE launch.
+        MultiArgs<EpiStore> ma;
+        BwdFinish fin;
+        fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R;
+        int np = 0, nf = 0;
         double flops = 0, bytes = 0;
+        const size_t slab = (size_t)B * R;
         for (int l = L - 1; l >= 0; --l) {
             const int s = TS - 1 - (dg - (L - 1 - l));
             if (s < 0 || s >= TS) continue;
             const bool top = l == L - 1, last = s == TS - 1;
-            EpiLstmBwd &e = ma.e[np];
+            EpiLstmBwd &e = fin.e[nf];
             e = EpiLstmBwd{};
             e.gates = c->Gt[l] + (size_t)s * B * 4 * R;
             e.c_prev = c->Cs[l] + (size_t)s * B * R;
@@ -520,23 +529,34 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
             e.R = R;
             e.sort_idx = c->sort_idx; e.B = B; e.T = TS; e.s = s; e.lm1 = l; e.dr = dr;
             e.has_upper = top ? 0 : 1;
-            // dh_s = dG_{s+1} W_h2h (none at the last step)  [+ Dropout'(dG^{l+1}_s W_i2h^{l+1}) below the top]
-            const float *A = last ? c->Gt[l] : c->Gt[l] + (size_t)(s + 1) * B * 4 * R;
-            GemmArgs &g = ma.g[np];
-            g = mkargs(A, 4 * R, c->P + c->lo.w_h2h[l], R, B, R, last ? 0 : 4 * R, 0, 0, c->nrows + s);
+            float *srec = c->chain_slabs + ((size_t)l * 2 + 0) * NVQA_BWD_Z * slab;
+            float *sup = c->chain_slabs + ((size_t)l * 2 + 1) * NVQA_BWD_Z * slab;
+            fin.srec[nf] = last ? nullptr : srec;
+            fin.sup[nf] = top ? nullptr : sup;
+            if (!last) {
+                ma.g[np] = mkargs(c->Gt[l] + (size_t)(s + 1) * B * 4 * R, 4 * R, c->P + c->lo.w_h2h[l], R, B, R, 4 * R,
+                                  4 * R / NVQA_BWD_Z, 0, c->nrows + s);
+                ma.e[np] = EpiStore{srec, R, slab};
+                ++np;
+            }
             if (!top) {
-                g.A2 = c->Gt[l + 1] + (size_t)s * B * 4 * R; g.lda2 = 4 * R;
-                g.B2 = c->P + c->lo.w_i2h[l + 1]; g.ldb2 = R; g.K2 = 4 * R;
+                ma.g[np] = mkargs(c->Gt[l + 1] + (size_t)s * B * 4 * R, 4 * R, c->P + c->lo.w_i2h[l + 1], R, B, R, 4 * R,
+                                  4 * R / NVQA_BWD_Z, 0, c->nrows + s);
+                ma.e[np] = EpiStore{sup, R, slab};
+                ++np;
             }
             const double nseg = (last ? 0 : 1) + (top ? 0 : 1);
             flops += 2.0 * B * 4 * R * R * nseg;
             bytes += ((double)B * 4 * R * (1 + nseg) + 4.0 * R * R * nseg + (double)B * R * 5) * 4;
-            ++np;
+            ++nf;
         }
-        {
-            ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
-            NVQA_HIP((launch_gemm_multi<CfgLstmBwd, A_KC, B_NC, false, EpiLstmBwd, 2>(c->s, ma, np)));
+        ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
+        if (np > 0) {
+            ma.zsplit = NVQA_BWD_Z;
+            NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
+        hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nf), dim3(256), 0, c->s, fin);
+        NVQA_HIP(hipGetLastError());
     }
     // Time-batched products, after the chains (run concurrently with them they only slow the
     // latency-critical step kernels down: measured 5.2 ms vs 4.5 ms per step): d(layer-0 input) on the
@@ -642,7 +662,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     {
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
         const int waves = 4;
-        const int blocks = (V + waves * NVQA_EB_ROWS - 1) / (waves * NVQA_EB_ROWS);
+        const int blocks = (V + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
         hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
                            c->ptok, c->X0, dX0, c->sort_idx, TB, B, T, V, E, dr, G + c->lo.w_e, 0);
     }
@@ -717,7 +737,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)(V + 1) * E) * 4);
         const int waves = 4;
-        const int blocks = (V + 1 + waves * NVQA_EB_ROWS - 1) / (waves * NVQA_EB_ROWS);
+        const int blocks = (V + 1 + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
         hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
                            c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
     }

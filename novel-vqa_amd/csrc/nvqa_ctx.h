@@ -99,6 +99,7 @@ struct nvqa_ctx {
     float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
     float *dqc = nullptr, *dic = nullptr;
     float *colpart = nullptr, *slabs = nullptr, *slabs2 = nullptr;
+    float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
     float *h_loss = nullptr; // pinned
