@@ -165,9 +165,15 @@ def main():
             pv = gemm[dom]
             avg_ms = pv["ms"] / pv["launches"]
             ach = pv["flops"] / pv["launches"] / (avg_ms * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled as
+            # MI355X_MICROARCH.md prescribes, + WRITE_SIZE), recorded by tools/pmc_traffic.py under profiles/
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "avg_launch_ms": round(avg_ms, 5),
                                "launches_per_step": pv["launches"] // nprof}
             out["kernel_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in prof.items()

@@ -222,10 +222,18 @@ __global__ void k_colsum_part(const float *X, int M, int N, int ld, int rows_per
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
     const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
-    float s = 0.f;
-    if (n < N)
-        for (int m = mbeg + w; m < mend; m += 4) s += X[(size_t)m * ld + n];
-    sm[w][threadIdx.x & 63] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f; // 4 independent chains keep 4+ loads in flight
+    if (n < N) {
+        int m = mbeg + w;
+        for (; m + 12 < mend; m += 16) {
+            s0 += X[(size_t)m * ld + n];
+            s1 += X[(size_t)(m + 4) * ld + n];
+            s2 += X[(size_t)(m + 8) * ld + n];
+            s3 += X[(size_t)(m + 12) * ld + n];
+        }
+        for (; m < mend; m += 4) s0 += X[(size_t)m * ld + n];
+    }
+    sm[w][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
@@ -233,8 +241,16 @@ __global__ void k_colsum_final(const float *part, int S, int N, float *out, floa
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    float s = 0.f;
-    for (int i = 0; i < S; ++i) s += part[(size_t)i * N + n];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < S; i += 4) {
+        s0 += part[(size_t)i * N + n];
+        s1 += part[(size_t)(i + 1) * N + n];
+        s2 += part[(size_t)(i + 2) * N + n];
+        s3 += part[(size_t)(i + 3) * N + n];
+    }
+    for (; i < S; ++i) s0 += part[(size_t)i * N + n];
+    const float s = (s0 + s1) + (s2 + s3);
     out[n] = s;
     if (out2) out2[n] = s;
 }
@@ -372,6 +388,25 @@ __global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int
     const float *src = Htop + ((size_t)tinfo[0] * B + b) * R;
     for (int j = threadIdx.x; j < R; j += blockDim.x)
         hd[(size_t)b * R + j] = dr.scale(NVQA_SITE_Q, (uint64_t)b * R + j) * src[j];
+}
+
+// ---------------------------------------------------------------------------------
+// AxB fusion finisher (misc/netdef.lua:10-12 + Dropout of 002_train_baseline.lua:153): the two
+// M = B projections W_q Dropout(q), W_v Dropout(v) run as ONE split-K multi-problem launch into
+// slabs (each alone has only 128 tiles); here: slab sums + bias, tanh, qc (*) ic, Dropout.
+// ---------------------------------------------------------------------------------
+__global__ void k_head_fuse(const float *sq, const float *sv, int Z, size_t n, int C, const float *bq,
+                            const float *bv, Drop dr, float *qc, float *ic, float *zd)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f, b = 0.f;
+    for (int z = 0; z < Z; ++z) { a += sq[(size_t)z * n + i]; b += sv[(size_t)z * n + i]; }
+    const int c = (int)(i % C);
+    const float q = tanhf_(a + bq[c]), v = tanhf_(b + bv[c]);
+    qc[i] = q;
+    ic[i] = v;
+    zd[i] = dr.scale(NVQA_SITE_Z, i) * (q * v);
 }
 
 // ---------------------------------------------------------------------------------

@@ -39,7 +39,7 @@ extern "C" const char *nvqa_last_error(void) { return g_err; }
 static const char *kProfNames[PF_COUNT] = {
     "assemble",      "emb_fwd",       "gemm_i2h_fwd", "lstm_step_fwd", "head_prep", "gemm_head_fwd",
     "softmax_ce",    "gemm_head_bwd", "lstm_step_bwd", "gemm_dgrad",   "gemm_wgrad", "reduce_slabs",
-    "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch"};
+    "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch", "lstm_bwd_finish"};
 
 struct ProfScope {
     nvqa_ctx *c;
@@ -499,9 +499,6 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
-    NVQA_HIP(hipEventRecord(c->evHead, c->s));
-    NVQA_HIP(hipStreamWaitEvent(c->sb, c->evHead, 0));
-    NVQA_HIP(hipStreamWaitEvent(c->sb2, c->evHead, 0));
     for (int dg = 0; dg < TS + L - 1; ++dg) {
         // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j).
         // Products of the level: dG_{s+1} W_h2h (none at the last step) and, below the top layer,
@@ -550,37 +547,33 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
             bytes += ((double)B * 4 * R * (1 + nseg) + 4.0 * R * R * nseg + (double)B * R * 5) * 4;
             ++nf;
         }
-        ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
         if (np > 0) {
+            ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z;
             NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
-        hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nf), dim3(256), 0, c->s, fin);
+        {
+            ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nf * slab * (2.0 * NVQA_BWD_Z + 14) * 4);
+            hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nf), dim3(256), 0, c->s, fin);
+        }
         NVQA_HIP(hipGetLastError());
     }
-    // Time-batched products, after the chains (run concurrently with them they only slow the
-    // latency-critical step kernels down: measured 5.2 ms vs 4.5 ms per step): d(layer-0 input) on the
-    // main stream, the weight gradients (sums over all steps, 002_train_baseline.lua:323-326) split
-    // over the two bulk streams.
-    NVQA_HIP(hipEventRecord(c->evB[0][0], c->s));
-    NVQA_HIP(hipStreamWaitEvent(c->sb, c->evB[0][0], 0));
-    NVQA_HIP(hipStreamWaitEvent(c->sb2, c->evB[0][0], 0));
+    // Time-batched products, after the chains, one after the other on the main stream: each of them
+    // fills the chip by itself (split-K), so extra streams bought nothing (measured), and overlapping
+    // them with the latency-critical chain kernels only slowed the chain (5.2 vs 4.5 ms per step).
+    // Weight gradients are sums over all steps (002_train_baseline.lua:323-326).
     for (int l = L - 1; l >= 0; --l) {
         const int in = l == 0 ? d.E : R;
         const float *Xin = l == 0 ? c->X0 : c->U[l];
-        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->sb));
-        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs2, c->sb2));
-        NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->sb2));
+        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s));
+        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s));
+        NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
     }
     if (dX0) {
         ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
         GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
         NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiStore{dX0, d.E, 0})));
     }
-    NVQA_HIP(hipEventRecord(c->evBulk, c->sb));
-    NVQA_HIP(hipEventRecord(c->evBulk2, c->sb2));
-    NVQA_HIP(hipStreamWaitEvent(c->s, c->evBulk, 0));
-    NVQA_HIP(hipStreamWaitEvent(c->s, c->evBulk2, 0));
     return 0;
 }
 
@@ -613,12 +606,26 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     {
         ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * ((double)C * Q + (double)C * I + (double)A * C),
                      ((double)C * Q + (double)C * I + (double)A * C) * 4);
-        // qc = tanh(W_q Dropout(q) + b_q)
-        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q),
-                                       EpiBiasTanh{c->qc, C, c->P + c->lo.b_q})));
-        // ic = tanh(W_v Dropout(v) + b_v); zd = Dropout(qc (*) ic)
-        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I),
-                                       EpiFuse{c->ic, c->zd, c->qc, c->P + c->lo.b_v, C, dr})));
+        // qc = tanh(W_q Dropout(q) + b_q), ic = tanh(W_v Dropout(v) + b_v), zd = Dropout(qc (*) ic):
+        // both projections as one split-K multi-problem launch into slabs, then k_head_fuse
+        const int Zh = 4;
+        const size_t nBC = (size_t)B * C;
+        if (Q % (32 * Zh) == 0 && I % (32 * Zh) == 0 && 2 * Zh * nBC <= c->slab_floats) {
+            MultiArgs<EpiStore> ma;
+            ma.g[0] = mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q, Q / Zh);
+            ma.e[0] = EpiStore{c->slabs, C, nBC};
+            ma.g[1] = mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I, I / Zh);
+            ma.e[1] = EpiStore{c->slabs + Zh * nBC, C, nBC};
+            ma.zsplit = Zh;
+            NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
+                               c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd);
+        } else {
+            NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q),
+                                           EpiBiasTanh{c->qc, C, c->P + c->lo.b_q})));
+            NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I),
+                                           EpiFuse{c->ic, c->zd, c->qc, c->P + c->lo.b_v, C, dr})));
+        }
         // scores = W_o zd + b_o
         NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->zd, C, c->P + c->lo.w_o, C, B, A, C),
                                        EpiBias2{c->scores, A, c->P + c->lo.b_o, nullptr})));

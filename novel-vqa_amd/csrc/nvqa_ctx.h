@@ -38,7 +38,7 @@ enum ProfId {
     PF_GEMM_HEAD_FWD,
     PF_SOFTMAX_CE,
     PF_GEMM_HEAD_BWD,
-    PF_LSTM_BWD,   // recurrent step: dgates x W_h2h + fused cell backward
+    PF_LSTM_BWD,   // BPTT level: split-K products dgates x W_h2h (and x W_i2h of the layer above)
     PF_GEMM_DGRAD, // time-batched d(input) products
     PF_GEMM_WGRAD, // time-batched weight gradients (split-K)
     PF_REDUCE,     // split-K slab sums
@@ -47,6 +47,7 @@ enum ProfId {
     PF_RMSPROP,
     PF_ALLREDUCE,
     PF_GATHER,
+    PF_LSTM_BWD_FIN, // slab sum + fused cell backward of one BPTT level
     PF_COUNT
 };
 

@@ -1,0 +1,58 @@
+"""Turns the rocprofv3 PMC passes of bench.py into per-launch HBM traffic per kernel group.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/write -- python3 bench.py ...
+    python pmc_traffic.py out/fetch out/write profiles/traffic.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of wide
+coalesced reads (MI355X_MICROARCH.md, HBM section): it is doubled here, as the guide prescribes.
+Kernel names are mapped to the group names of nvqa_profile_name().
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+GROUPS = [
+    ("lstm_step_fwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiLstmFwd" in n),
+    ("lstm_step_bwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiStore" in n),
+    ("lstm_bwd_finish", lambda n: "k_lstm_bwd_finish" in n),
+    ("gemm_wgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n),
+    ("gemm_i2h_fwd", lambda n: "gemm_f32_kernel" in n and "EpiBias2" in n and "128, 64" in n),
+    ("gemm_dgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 0, 1, false" in n and "EpiStore" in n),
+    ("rmsprop", lambda n: "k_rmsprop" in n),
+    ("emb_bwd", lambda n: "k_emb_bwd" in n),
+    ("emb_fwd", lambda n: "k_emb_fwd" in n),
+    ("softmax_ce", lambda n: "k_softmax_ce" in n),
+]
+
+
+def collect(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        for g, pred in GROUPS:
+            if pred(r["Kernel_Name"]):
+                agg[g] += float(r["Counter_Value"])
+                cnt[g] += 1
+                break
+    return {g: agg[g] / cnt[g] for g in agg}
+
+
+def main():
+    fetch = collect(sys.argv[1], "FETCH_SIZE")
+    write = collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for g in sorted(set(fetch) | set(write)):
+        fb = 2.0 * fetch.get(g, 0.0) * 1024  # gfx950: FETCH_SIZE counts 64 B per 128-B request
+        wb = write.get(g, 0.0) * 1024
+        out[g] = {"hbm_bytes_per_launch": round(fb + wb), "fetch_bytes_corrected": round(fb), "write_bytes": round(wb)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
