@@ -118,8 +118,10 @@ int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t 
                  const float *img, float *scores_out, int32_t *argmax_out);
 
 /* clamp -> (+ wd * x) -> m = alpha m + (1-alpha) g^2 -> x -= lr g / (sqrt(m) + eps).
- * With a communicator the gradient is first summed over ranks and divided by
- * the world size; the clamp acts on that average. */
+ * With a communicator (nvqa_comm_init) nvqa_step itself sums the gradient over the ranks,
+ * one all-reduce per parameter segment overlapped with the backward pass; the update then
+ * divides by the world size and the clamp acts on that average.  nvqa_get_grads returns the
+ * same average. */
 int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
 
 /* ---- HBM-resident dataset (the tensors of 002_train_baseline.lua:93-121) ---- */

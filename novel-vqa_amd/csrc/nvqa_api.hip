@@ -128,6 +128,8 @@ static inline Drop mkdrop(const nvqa_dropout *dr, bool train)
     return d;
 }
 
+static void comm_destroy(nvqa_ctx *c); // with the RCCL loader, below
+
 // ------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------
@@ -180,6 +182,9 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
         for (int l = 1; l < d.L; ++l) NVQA_HIP(hipStreamCreateWithPriority(&c->sl[l], hipStreamNonBlocking, greatest));
         NVQA_HIP(hipStreamCreateWithPriority(&c->sb, hipStreamNonBlocking, least));
         NVQA_HIP(hipStreamCreateWithPriority(&c->sb2, hipStreamNonBlocking, least));
+        NVQA_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, greatest));
+        for (int i = 0; i < 3; ++i) NVQA_HIP(hipEventCreateWithFlags(&c->evSeg[i], hipEventDisableTiming));
+        NVQA_HIP(hipEventCreateWithFlags(&c->evComm, hipEventDisableTiming));
         c->sl[0] = c->s;
         for (int l = 0; l < d.L; ++l) {
             c->evF[l].resize(c->TS);
@@ -261,6 +266,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     prof_collect(c);
+    comm_destroy(c);
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
                     c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->slabs2, c->chain_slabs,
@@ -284,6 +290,9 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
         if (e) (void)hipEventDestroy(e);
     if (c->sb) (void)hipStreamDestroy(c->sb);
     if (c->sb2) (void)hipStreamDestroy(c->sb2);
+    if (c->sc) (void)hipStreamDestroy(c->sc);
+    for (hipEvent_t e : {c->evSeg[0], c->evSeg[1], c->evSeg[2], c->evComm})
+        if (e) (void)hipEventDestroy(e);
     if (c->s) (void)hipStreamDestroy(c->s);
     delete c;
     return 0;
@@ -371,7 +380,8 @@ extern "C" int nvqa_init_params(nvqa_ctx *c, uint64_t seed, float lo, float hi)
     return 0;
 }
 
-static int allreduce_grads(nvqa_ctx *c); // below
+static int reduce_segment(nvqa_ctx *c, int seg); // below: RCCL sum of one parameter segment, overlapped
+static int reduce_join(nvqa_ctx *c);
 
 extern "C" int nvqa_get_grads(nvqa_ctx *c, float *out, float clamp)
 {
@@ -381,6 +391,9 @@ extern "C" int nvqa_get_grads(nvqa_ctx *c, float *out, float clamp)
     std::vector<float> in(c->lo.total);
     NVQA_HIP(hipStreamSynchronize(c->s));
     NVQA_HIP(hipMemcpy(in.data(), c->G, c->lo.total * 4, hipMemcpyDeviceToHost));
+    // with a communicator the device buffer holds the sum over ranks: return the global-batch mean
+    if (c->comm && c->world > 1)
+        for (float &v : in) v *= 1.0f / (float)c->world;
     if (clamp > 0.f)
         for (float &v : in) v = std::min(std::max(v, -clamp), clamp);
     to_abi(c, in, out);
@@ -664,8 +677,10 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
     NVQA_TRY(colsum(c, c->dqc, B, C, C, G + c->lo.b_q, nullptr));
     NVQA_TRY(colsum(c, c->dic, B, C, C, G + c->lo.b_v, nullptr));
+    NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
     float *dX0 = c->dX0;
     NVQA_TRY(lstm_backward(c, dr, dX0));
+    NVQA_TRY(reduce_segment(c, 0)); // encoder
     {
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
         const int waves = 4;
@@ -675,6 +690,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     }
     NVQA_HIP(hipGetLastError());
     NVQA_TRY(colsum(c, G + c->lo.w_e, V, E, E, G + c->lo.b_e, nullptr));
+    NVQA_TRY(reduce_segment(c, 1)); // embedding
     return 0;
 }
 
@@ -735,6 +751,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
                                        EpiHead2{c->dHT + (size_t)(L - 1) * B * R, R, dr})));
     }
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
+    NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr, c->dX0));
     {   // cnn_projection:backward (002_train_baseline.lua:322): dW_p = dx_1^T fv_im, db_p = colsum(dx_1)
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 2.0 * B * E * I, ((double)B * (E + I) + (double)E * I) * 4);
@@ -749,6 +766,8 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
                            c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
     }
     NVQA_HIP(hipGetLastError());
+    NVQA_TRY(reduce_segment(c, 0)); // cnn projection
+    NVQA_TRY(reduce_segment(c, 1)); // encoder (LSTM + lookup table)
     return 0;
 }
 
@@ -765,6 +784,7 @@ static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
         NVQA_TRY(arch2_forward(c, dr, true, false));
         NVQA_TRY(arch2_backward(c, dr));
     }
+    NVQA_TRY(reduce_join(c));
     c->have_grads = true;
     NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
     if (loss_out) {
@@ -859,7 +879,6 @@ extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps
     if (!c) { set_error("ctx is NULL"); return -1; }
     if (!c->have_grads) { set_error("nvqa_rmsprop_update before any nvqa_step"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
-    NVQA_TRY(allreduce_grads(c));
     ProfScope ps(c, PF_RMSPROP, 0, 20.0 * c->lo.total);
     const size_t n4 = c->lo.total / 4; // every tensor size is a multiple of 4 (check_dims)
     hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
@@ -998,13 +1017,33 @@ extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
     return 0;
 }
 
-static int allreduce_grads(nvqa_ctx *c)
+// Gradient exchange: one ncclAllReduce(sum) per parameter segment, issued on the communication
+// stream as soon as the segment's gradients are final (backward-completion order: multimodal,
+// encoder, embedding), so the largest bucket travels over xGMI while BPTT is still running.
+// The 1/world scale and the clamp stay in k_rmsprop: the clamp must act on the mean
+// (002_train_baseline.lua:329 is non-linear).  Every rank issues the same calls in the same order.
+static int reduce_segment(nvqa_ctx *c, int seg)
 {
-    if (!c->comm || c->world == 1) return 0;
-    ProfScope ps(c, PF_ALLREDUCE, 0, 4.0 * c->lo.total);
-    // one sum over the flat gradient; the 1/world scale and the clamp run in k_rmsprop
-    const int rc = g_rccl.AllReduce(c->G, c->G, c->lo.total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->s);
+    if (!c->comm) return 0;
+    size_t off = 0;
+    for (int i = 0; i < seg; ++i) off += c->lo.seg[i];
+    NVQA_HIP(hipEventRecord(c->evSeg[seg], c->s));
+    NVQA_HIP(hipStreamWaitEvent(c->sc, c->evSeg[seg], 0));
+    ProfScope ps(c, PF_ALLREDUCE, 0, 4.0 * c->lo.seg[seg], c->sc);
+    const int rc = g_rccl.AllReduce(c->G + off, c->G + off, c->lo.seg[seg], /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
     if (rc) { set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    return 0;
+}
+static void comm_destroy(nvqa_ctx *c)
+{
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+}
+static int reduce_join(nvqa_ctx *c)
+{
+    if (!c->comm) return 0;
+    NVQA_HIP(hipEventRecord(c->evComm, c->sc));
+    NVQA_HIP(hipStreamWaitEvent(c->s, c->evComm, 0));
     return 0;
 }
 

@@ -74,6 +74,8 @@ struct nvqa_ctx {
     hipStream_t sb = nullptr, sb2 = nullptr;     // bulk streams: time-chunked weight gradients (low priority)
     std::vector<hipEvent_t> evF[NVQA_MAX_LAYERS], evB[NVQA_MAX_LAYERS]; // per layer, per step
     hipEvent_t evHead = nullptr, evBulk = nullptr, evBulk2 = nullptr, evStart = nullptr;
+    hipStream_t sc = nullptr;                    // communication stream (RCCL all-reduce buckets)
+    hipEvent_t evSeg[3] = {}, evComm = nullptr;  // segment ready / exchange done
     int TS = 0; // recurrent steps: arch1 T, arch2 T+2
 
     // parameters / gradients / RMSprop mean-square (internal layout = ABI layout with the
