@@ -1,0 +1,84 @@
+"""BASELINE.json configs[1] at full size (arch1, B=512, T=26, V=14773, 4096-d features, 1000 answers):
+parity against the oracle where it is cheap enough, and size-independent properties of the domain:
+bit-reproducibility (no float atomics anywhere), batch-permutation invariance, equivalence of the
+HBM-resident dataset path (next_batch gather on the device) with the host-batch path, and a
+decreasing loss over a few RMSprop iterations."""
+import numpy as np
+import pytest
+
+from util import gdims, gdrop, relmax, segment_errors
+
+pytestmark = pytest.mark.gpu
+FULL = dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000)
+
+
+@pytest.fixture(scope="module")
+def setup(orc):
+    d = orc.make_dims(**FULL)
+    return d, orc.synth_params(d), orc.synth_batch(d, full_length=False, min_len=3)
+
+
+def test_full_size_step_matches_oracle(pkg, orc, setup):
+    d, params, (tok, lens, img, lab) = setup
+    dr = orc.Dropout(1, 0.5, 123, 9)
+    ref = orc.Oracle(np.float32).step(d, params, tok, lens, img, lab, dr)  # fp32 oracle: a few seconds
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    loss = ctx.step(tok, lens, img, lab, gdrop(pkg, dr))
+    grads = ctx.get_grads()
+    assert abs(loss - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    bad = {k: e for k, e in segment_errors(orc, d, grads, ref["grads"]).items() if e > 2e-3}
+    assert not bad, bad
+    ev = orc.Oracle(np.float32).step(d, params, tok, lens, img, lab, None, train=False)
+    scores, argmax = ctx.forward(tok, lens, img)
+    assert relmax(scores, ev["scores"]) <= 1e-4
+    top2 = np.sort(ev["scores"], 1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * np.abs(top2[:, 1])
+    assert clear.mean() > 0.9 and np.array_equal(argmax[clear], ev["argmax"][clear])
+    ctx.close()
+
+
+def test_bit_reproducible_and_permutation_invariant(pkg, orc, setup):
+    d, params, (tok, lens, img, lab) = setup
+    dr = pkg.binding.Dropout(0, 0.5, 123, 0)
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    l1 = ctx.step(tok, lens, img, lab, dr)
+    g1 = ctx.get_grads()
+    l2 = ctx.step(tok, lens, img, lab, dr)
+    g2 = ctx.get_grads()
+    assert l1 == l2 and np.array_equal(g1, g2), "two runs of the same step must be bit-identical"
+    perm = np.random.default_rng(3).permutation(d.B)
+    l3 = ctx.step(tok[perm], lens[perm], img[perm], lab[perm], dr)
+    g3 = ctx.get_grads()
+    assert abs(l3 - l1) <= 2e-6 * abs(l1)
+    assert relmax(g3, g1) < 1e-4  # only the fp32 summation order over the batch changes
+    ctx.close()
+
+
+def test_dataset_path_equals_host_batch_path_and_trains(pkg, orc, setup):
+    d, params, (tok, lens, img, lab) = setup
+    rng = np.random.default_rng(4)
+    n_img = 300
+    feats = np.abs(rng.standard_normal((n_img, d.I))).astype(np.float32)
+    img_pos = rng.integers(1, n_img + 1, d.B).astype(np.int32)
+    tr = pkg.trainer.VQATrainer(gdims(pkg, d), 0, seed=123, dropout=True)
+    tr.set_params(params)
+    tr.load_dataset(tok, lens, img_pos, lab, feats, img_norm=True)
+    qinds = rng.permutation(d.B).astype(np.int64)
+    dr = tr._dropout()
+    la = tr.ctx.step_indices(qinds, dr)
+    ga = tr.ctx.get_grads()
+    fn = feats / np.sqrt((feats * feats).sum(1, keepdims=True))
+    lb = tr.ctx.step(tok[qinds], lens[qinds], fn[img_pos[qinds] - 1], lab[qinds], dr)
+    gb = tr.ctx.get_grads()
+    assert abs(la - lb) <= 1e-6 * abs(lb) and relmax(ga, gb) < 1e-5
+    # a few iterations of the reference's loop: JdJ + rmsprop, loss must go down on a fixed batch
+    first = last = None
+    for it in range(8):
+        f = tr.ctx.step_indices(qinds, tr._dropout())
+        tr.rmsprop()
+        first = f if first is None else first
+        last = f
+    assert last < first
+    tr.close()
