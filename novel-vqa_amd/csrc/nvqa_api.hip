@@ -582,11 +582,18 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
         NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s));
         NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
     }
-    if (dX0) {
-        ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
-        GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
-        NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiStore{dX0, d.E, 0})));
-    }
+    return 0;
+}
+
+// dL/d(layer-0 input) for all steps at once; runs after the LSTM weight gradients so that their
+// all-reduce (data parallel) overlaps it.
+static int lstm_dx0(nvqa_ctx *c, float *dX0)
+{
+    const nvqa_dims &d = c->d;
+    const int R = d.R, TB = c->TS * d.B;
+    ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
+    GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
+    NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiStore{dX0, d.E, 0})));
     return 0;
 }
 
@@ -680,7 +687,8 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
     float *dX0 = c->dX0;
     NVQA_TRY(lstm_backward(c, dr, dX0));
-    NVQA_TRY(reduce_segment(c, 0)); // encoder
+    NVQA_TRY(reduce_segment(c, 0)); // encoder: overlaps d(input), the embedding gradient and its column sum
+    NVQA_TRY(lstm_dx0(c, dX0));
     {
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
         const int waves = 4;
@@ -753,6 +761,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
     NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr, c->dX0));
+    NVQA_TRY(lstm_dx0(c, c->dX0));
     {   // cnn_projection:backward (002_train_baseline.lua:322): dW_p = dx_1^T fv_im, db_p = colsum(dx_1)
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 2.0 * B * E * I, ((double)B * (E + I) + (double)E * I) * 4);
         NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dX0, E, c->img, I, E, I, B), EpiStore{G + c->lo.w_p, I, 0})));

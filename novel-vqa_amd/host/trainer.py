@@ -16,7 +16,7 @@ device-side update, `next_batch()` mirrors dataset:next_batch() (:195-222),
 """
 import numpy as np
 
-from . import binding
+from . import binding, t7
 
 DECAY_FACTOR = 0.99997592083  # 002_train_baseline.lua:78
 
@@ -97,6 +97,13 @@ class VQATrainer:
             scores.append(sc)
             preds.append(am)
         return np.concatenate(scores), np.concatenate(preds)
+
+    # -- torch.save / torch.load of the reference's checkpoint table (:401-402, 004_eval_model.lua:154-163)
+    def save_checkpoint(self, path):
+        t7.save_checkpoint(path, self.dims.arch, self.get_params(), self.ctx.segments())
+
+    def load_checkpoint(self, path):
+        self.set_params(t7.load_checkpoint(path, self.dims.arch, self.ctx.segments()))
 
     def close(self):
         self.ctx.close()
