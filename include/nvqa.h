@@ -124,9 +124,19 @@ int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t 
  * same average. */
 int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
 
+/* ---- model variants of the reference's other training scripts -------------- */
+/* askip = 1: netdef.AskipB fusion, output = qc + qc (*) ic (misc/netdef.lua:16-25,
+ * 003_train_ae_based_wp.lua:151) instead of netdef.AxB.  arch1 only. */
+int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
+/* Per-segment gradient scale applied before the clamp: {lr_scale, lr_scale, 1} reproduces
+ * -lr_scale of 003_train_ae_based_wp.lua:30,344. */
+int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);
+
 /* ---- HBM-resident dataset (the tensors of 002_train_baseline.lua:93-121) ---- */
 /* questions [N x T] (aligned as nvqa_step expects), lengths [N], img_pos [N]
- * (1-based rows of feats), answers [N] (1-based), feats [N_img x I]. */
+ * (1-based rows of feats), answers [N] (1-based), feats [N_img x I].
+ * l2_normalize: 0 = keep, 1 = row L2 norm (002_train_baseline.lua:117-121), n > 1 = the two blocks
+ * [0,n) and [n,I) normalised separately (early fusion, 003_train_ae_based_ef.lua:115-119, n = 2048). */
 int nvqa_dataset_load(nvqa_ctx *ctx, int64_t n_q, const int32_t *questions, const int32_t *lengths,
                       const int32_t *img_pos, const int32_t *answers, int64_t n_img,
                       const float *feats, int l2_normalize);

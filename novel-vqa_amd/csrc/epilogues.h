@@ -74,12 +74,13 @@ struct EpiFuse {
     const float *qc, *b;
     int ldc;
     Drop dr;
+    int askip; // netdef.AskipB (misc/netdef.lua:16-25): qc + qc (*) ic
     __device__ __forceinline__ void operator()(int, int m, int n, float v) const
     {
         const size_t o = (size_t)m * ldc + n;
         const float i = tanhf_(v + b[n]);
         ic[o] = i;
-        zd[o] = dr.scale(NVQA_SITE_Z, o) * (qc[o] * i);
+        zd[o] = dr.scale(NVQA_SITE_Z, o) * (askip ? qc[o] + qc[o] * i : qc[o] * i);
     }
 };
 
@@ -89,12 +90,13 @@ struct EpiHeadBwd {
     const float *qc, *ic;
     int ldc;
     Drop dr;
+    int askip;
     __device__ __forceinline__ void operator()(int, int m, int n, float v) const
     {
         const size_t o = (size_t)m * ldc + n;
         const float dz = dr.scale(NVQA_SITE_Z, o) * v;
         const float q = qc[o], i = ic[o];
-        dqc[o] = dz * i * (1.0f - q * q);
+        dqc[o] = dz * (askip ? 1.0f + i : i) * (1.0f - q * q);
         dic[o] = dz * q * (1.0f - i * i);
     }
 };

@@ -43,12 +43,14 @@ __global__ void k_gather_batch(const int64_t *qinds, const int32_t *Q, const int
 }
 
 // row L2 normalisation (002_train_baseline.lua:117-121), one wave per row, in place
-__global__ void k_l2norm_rows(float *F, int64_t n, int I)
+// (columns [col0, col0 + I) of rows of width ld: early fusion normalises two blocks separately,
+// 003_train_ae_based_ef.lua:115-119)
+__global__ void k_l2norm_rows(float *F, int64_t n, int ld, int col0, int I)
 {
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
-    float4 *p = reinterpret_cast<float4 *>(F + row * I);
+    float4 *p = reinterpret_cast<float4 *>(F + row * ld + col0);
     float s = 0.f;
     for (int i = lane; i < I / 4; i += 64) {
         const float4 v = p[i];
@@ -396,7 +398,7 @@ __global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int
 // slabs (each alone has only 128 tiles); here: slab sums + bias, tanh, qc (*) ic, Dropout.
 // ---------------------------------------------------------------------------------
 __global__ void k_head_fuse(const float *sq, const float *sv, int Z, size_t n, int C, const float *bq,
-                            const float *bv, Drop dr, float *qc, float *ic, float *zd)
+                            const float *bv, Drop dr, float *qc, float *ic, float *zd, int askip)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -406,7 +408,7 @@ __global__ void k_head_fuse(const float *sq, const float *sv, int Z, size_t n, i
     const float q = tanhf_(a + bq[c]), v = tanhf_(b + bv[c]);
     qc[i] = q;
     ic[i] = v;
-    zd[i] = dr.scale(NVQA_SITE_Z, i) * (q * v);
+    zd[i] = dr.scale(NVQA_SITE_Z, i) * (askip ? q + q * v : q * v); // netdef.AskipB : netdef.AxB
 }
 
 // ---------------------------------------------------------------------------------

@@ -392,8 +392,15 @@ extern "C" int nvqa_get_grads(nvqa_ctx *c, float *out, float clamp)
     NVQA_HIP(hipStreamSynchronize(c->s));
     NVQA_HIP(hipMemcpy(in.data(), c->G, c->lo.total * 4, hipMemcpyDeviceToHost));
     // with a communicator the device buffer holds the sum over ranks: return the global-batch mean
-    if (c->comm && c->world > 1)
-        for (float &v : in) v *= 1.0f / (float)c->world;
+    {
+        size_t off = 0;
+        for (int sgm = 0; sgm < 3; ++sgm) {
+            const float sc = c->gscale[sgm] * ((c->comm && c->world > 1) ? 1.0f / (float)c->world : 1.0f);
+            if (sc != 1.0f)
+                for (size_t i = 0; i < c->lo.seg[sgm]; ++i) in[off + i] *= sc;
+            off += c->lo.seg[sgm];
+        }
+    }
     if (clamp > 0.f)
         for (float &v : in) v = std::min(std::max(v, -clamp), clamp);
     to_abi(c, in, out);
@@ -639,12 +646,12 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             ma.zsplit = Zh;
             NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
-                               c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd);
+                               c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
         } else {
             NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q),
                                            EpiBiasTanh{c->qc, C, c->P + c->lo.b_q})));
             NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I),
-                                           EpiFuse{c->ic, c->zd, c->qc, c->P + c->lo.b_v, C, dr})));
+                                           EpiFuse{c->ic, c->zd, c->qc, c->P + c->lo.b_v, C, dr, c->fusion_askip})));
         }
         // scores = W_o zd + b_o
         NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->zd, C, c->P + c->lo.w_o, C, B, A, C),
@@ -674,7 +681,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
         // classifier: dW_o = dscores^T zd ; d(zd) = dscores W_o -> Dropout', CMul', Tanh'
         NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, C, A, C, B), EpiStore{G + c->lo.w_o, C, 0})));
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, C, B, C, A),
-                                       EpiHeadBwd{c->dqc, c->dic, c->qc, c->ic, C, dr})));
+                                       EpiHeadBwd{c->dqc, c->dic, c->qc, c->ic, C, dr, c->fusion_askip})));
         // fusion: dW_q = dqc^T qd ; dW_v = dic^T vd ; d(qd) = dqc W_q (no gradient to the image)
         NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dqc, C, c->qd, Q, C, Q, B), EpiStore{G + c->lo.w_q, Q, 0})));
         NVQA_TRY((gemm_big<A_MC, B_NC>(c, mkargs(c->dic, C, c->vd, I, C, I, B), EpiStore{G + c->lo.w_v, I, 0})));
@@ -874,6 +881,20 @@ extern "C" int nvqa_forward(nvqa_ctx *c, int32_t n, const int32_t *tokens, const
     return 0;
 }
 
+// model variants of the reference's other training scripts
+extern "C" int nvqa_set_fusion(nvqa_ctx *c, int askip)
+{
+    if (!c || c->d.arch != NVQA_ARCH1 || (askip != 0 && askip != 1)) { set_error("nvqa_set_fusion: arch1 context and mode 0/1 expected"); return -1; }
+    c->fusion_askip = askip;
+    return 0;
+}
+extern "C" int nvqa_set_grad_scales(nvqa_ctx *c, const float scales[3])
+{
+    if (!c || !scales) { set_error("NULL argument"); return -1; }
+    for (int i = 0; i < 3; ++i) c->gscale[i] = scales[i];
+    return 0;
+}
+
 extern "C" int nvqa_get_loss(nvqa_ctx *c, float *loss_out)
 {
     if (!c || !loss_out) { set_error("NULL argument"); return -1; }
@@ -889,10 +910,22 @@ extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps
     if (!c->have_grads) { set_error("nvqa_rmsprop_update before any nvqa_step"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     ProfScope ps(c, PF_RMSPROP, 0, 20.0 * c->lo.total);
-    const size_t n4 = c->lo.total / 4; // every tensor size is a multiple of 4 (check_dims)
-    hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
-                       reinterpret_cast<const float4 *>(c->G), reinterpret_cast<float4 *>(c->M2), n4, lr, alpha,
-                       eps, wd, clamp, 1.0f / (float)c->world);
+    const float inv_world = 1.0f / (float)c->world;
+    if (c->gscale[0] == c->gscale[1] && c->gscale[1] == c->gscale[2]) {
+        const size_t n4 = c->lo.total / 4; // every tensor size is a multiple of 4 (check_dims)
+        hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
+                           reinterpret_cast<const float4 *>(c->G), reinterpret_cast<float4 *>(c->M2), n4, lr, alpha,
+                           eps, wd, clamp, inv_world * c->gscale[0]);
+    } else { // -lr_scale of 003_train_ae_based_wp.lua:344: encoder / embedding gradients scaled before the clamp
+        size_t off = 0;
+        for (int sgm = 0; sgm < 3; ++sgm) {
+            const size_t n4 = c->lo.seg[sgm] / 4;
+            hipLaunchKernelGGL(k_rmsprop, dim3(1024), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P + off),
+                               reinterpret_cast<const float4 *>(c->G + off), reinterpret_cast<float4 *>(c->M2 + off), n4,
+                               lr, alpha, eps, wd, clamp, inv_world * c->gscale[sgm]);
+            off += c->lo.seg[sgm];
+        }
+    }
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -942,8 +975,14 @@ extern "C" int nvqa_dataset_load(nvqa_ctx *c, int64_t n_q, const int32_t *questi
     }
     ds.n_q = n_q;
     ds.n_img = n_img;
-    if (l2_normalize) {
-        hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I);
+    if (l2_normalize > 1 && (l2_normalize >= d.I || l2_normalize % 4)) { set_error("l2_normalize split %d must be a multiple of 4 below I=%d", l2_normalize, d.I); return -1; }
+    if (l2_normalize > 1) {
+        hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I, 0, l2_normalize);
+        hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I, l2_normalize, d.I - l2_normalize);
+        NVQA_HIP(hipGetLastError());
+        NVQA_HIP(hipStreamSynchronize(c->s));
+    } else if (l2_normalize) {
+        hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I, 0, d.I);
         NVQA_HIP(hipGetLastError());
         NVQA_HIP(hipStreamSynchronize(c->s));
     }

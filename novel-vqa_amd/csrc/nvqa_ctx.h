@@ -82,6 +82,8 @@ struct nvqa_ctx {
     // arch1 embedding table transposed to [V][E])
     float *P = nullptr, *G = nullptr, *M2 = nullptr;
     bool have_grads = false;
+    int fusion_askip = 0;             // 0 netdef.AxB, 1 netdef.AskipB
+    float gscale[3] = {1.f, 1.f, 1.f}; // per-segment gradient scale before the clamp (-lr_scale)
 
     // current batch
     int32_t *tok = nullptr, *len = nullptr, *lab = nullptr;

@@ -50,6 +50,8 @@ SYMBOLS = {
     "nvqa_get_loss": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_forward": (ctypes.c_int, [_vp, ctypes.c_int32, _i32p, _i32p, _f32p, _f32p, _i32p]),
     "nvqa_rmsprop_update": (ctypes.c_int, [_vp] + [ctypes.c_float] * 5),
+    "nvqa_set_fusion": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "nvqa_set_grad_scales": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_dataset_load": (ctypes.c_int, [_vp, ctypes.c_int64, _i32p, _i32p, _i32p, _i32p,
                                          ctypes.c_int64, _f32p, ctypes.c_int]),
     "nvqa_step_indices": (ctypes.c_int, [_vp, _i64p, ctypes.POINTER(Dropout), _f32p]),
@@ -195,6 +197,14 @@ class Context:
 
     def rmsprop_update(self, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
         self._check(self.lib.nvqa_rmsprop_update(self._h, lr, alpha, eps, wd, clamp))
+
+    def set_fusion(self, askip):
+        self._check(self.lib.nvqa_set_fusion(self._h, int(askip)))
+
+    def set_grad_scales(self, scales):
+        a = np.ascontiguousarray(scales, np.float32)
+        assert a.size == 3
+        self._check(self.lib.nvqa_set_grad_scales(self._h, _f32(a)))
 
     def sync(self):
         self._check(self.lib.nvqa_sync(self._h))

@@ -53,8 +53,9 @@ class VQATrainer:
 
     # -- dataset:next_batch() -------------------------------------------------------------------
     def load_dataset(self, questions, lengths, img_pos, answers, feats, img_norm=True):
-        """dataset[...] tensors (:93-121); right_align must already be applied for arch1."""
-        self.ctx.dataset_load(questions, lengths, img_pos, answers, feats, l2_normalize=img_norm)
+        """dataset[...] tensors (:93-121); right_align must already be applied for arch1.
+        img_norm: False/True, or an int split n > 1 for the early-fusion two-block norm."""
+        self.ctx.dataset_load(questions, lengths, img_pos, answers, feats, l2_normalize=int(img_norm))
         self.n_questions = int(np.asarray(questions).shape[0])
 
     def next_batch(self):
@@ -107,6 +108,17 @@ class VQATrainer:
 
     def close(self):
         self.ctx.close()
+
+
+def late_fusion(scores_a, scores_b, weight_a=1.0, weight_b=1.0):
+    """004_eval_model_lf.lua:109-132: weighted sum of two models' answer scores."""
+    return weight_a * np.asarray(scores_a, np.float64) + weight_b * np.asarray(scores_b, np.float64)
+
+
+def results_json(question_ids, answer_ids, ix_to_ans):
+    """The reference's result file: [{question_id, answer}] with answers looked up by their 1-based
+    id in json_file['ix_to_ans'] (004_eval_model.lua:249-255); feed to json.dump."""
+    return [{"question_id": int(q), "answer": ix_to_ans[str(int(a))]} for q, a in zip(question_ids, answer_ids)]
 
 
 def multiple_choice_argmax(scores, mc_ans):

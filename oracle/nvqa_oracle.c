@@ -174,6 +174,11 @@ static real softmax_ce(int B, int A, const real *scores, const int32_t *labels, 
 /* train != 0: training-mode forward (dropout per `dr`) + backward into grads
  * (flat, reference layout, UNclamped).  train == 0: evaluate mode, forward
  * only.  scores [B x A] / argmax [B] optional outputs.  Returns 0 / <0. */
+/* fusion graph: 0 = netdef.AxB (misc/netdef.lua:6-14, the baseline), 1 = netdef.AskipB
+ * (misc/netdef.lua:16-25: output = qc + qc (*) ic, used by 003_train_ae_based_wp.lua:151) */
+static int g_fusion_askip = 0;
+void oracle_set_fusion(int askip) { g_fusion_askip = askip; }
+
 int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok,
                       const int32_t *len, const real *img, const int32_t *labels,
                       const nvqa_dropout *dr_in, int train, real *loss_out, real *grads,
@@ -292,7 +297,7 @@ int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok
         qc[z] = (real)tanh((double)qc[z]);
         ic[z] = (real)tanh((double)ic[z]);
         Dz[z] = drop_scale(dr, NVQA_SITE_Z, z);
-        zd[z] = Dz[z] * (qc[z] * ic[z]);
+        zd[z] = Dz[z] * (g_fusion_askip ? qc[z] + qc[z] * ic[z] : qc[z] * ic[z]);
     }
     real *scores = zalloc((size_t)B * A), *dscores = zalloc((size_t)B * A);
     lin_fwd(B, A, C, zd, params + lo.w_o, params + lo.b_o, scores);
@@ -308,7 +313,7 @@ int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok
         lin_bwd_dx(B, A, C, dscores, params + lo.w_o, dzd, 0);
         for (size_t z = 0; z < (size_t)B * C; ++z) {
             const real dz = Dz[z] * dzd[z];
-            dqc[z] = dz * ic[z] * ((real)1 - qc[z] * qc[z]);
+            dqc[z] = dz * (g_fusion_askip ? (real)1 + ic[z] : ic[z]) * ((real)1 - qc[z] * qc[z]);
             dic[z] = dz * qc[z] * ((real)1 - ic[z] * ic[z]);
         }
         lin_bwd_dw(B, C, Q, dqc, qd, grads + lo.w_q, grads + lo.b_q);

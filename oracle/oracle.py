@@ -140,6 +140,10 @@ class Oracle:
             raise RuntimeError(f"oracle step failed rc={rc}")
         return {"loss": float(loss.value), "grads": grads, "scores": scores, "argmax": argmax}
 
+    def set_fusion(self, askip):
+        """0 = netdef.AxB, 1 = netdef.AskipB (process-wide switch of the oracle library)."""
+        self.lib.oracle_set_fusion(int(askip))
+
     def rmsprop(self, x, g, m, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
         """In place on x, g (clamped, + wd x), m."""
         for a in (x, g, m):

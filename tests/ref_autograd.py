@@ -53,7 +53,7 @@ def _cell(a, c_prev, R):
     return c, o * torch.tanh(c)
 
 
-def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True):
+def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True, askip=False):
     d = dims
     B, T, V, E, R, L, I, C, A = d.B, d.T, d.V, d.E, d.R, d.L, d.I, d.C, d.A
     params = torch.tensor(np.asarray(params_np, np.float64), requires_grad=True)
@@ -90,7 +90,8 @@ def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True
     v = torch.tensor(np.asarray(img, np.float64).reshape(B, I))
     qc = torch.tanh((Dq * q) @ p["w_q"].view(C, Q).t() + p["b_q"])
     ic = torch.tanh((Dv * v) @ p["w_v"].view(C, I).t() + p["b_v"])
-    scores = (Dz * (qc * ic)) @ p["w_o"].view(A, C).t() + p["b_o"]
+    fused = qc + qc * ic if askip else qc * ic  # netdef.AskipB / netdef.AxB
+    scores = (Dz * fused) @ p["w_o"].view(A, C).t() + p["b_o"]
     y = torch.tensor(np.asarray(labels, np.int64) - 1)
     loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
     grads = None

@@ -1,0 +1,84 @@
+"""Model variants of the reference's other training scripts on the HIP path:
+AskipB fusion, -lr_scale, early-fusion two-block feature normalisation."""
+import numpy as np
+import pytest
+
+from util import gdims, gdrop, relmax, segment_errors
+
+pytestmark = pytest.mark.gpu
+KW = dict(arch=1, B=9, T=7, V=50, E=12, R=16, L=2, I=32, C=24, A=12)
+
+
+def test_askipb_fusion(pkg, orc):
+    d = orc.make_dims(**KW)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    dr = orc.Dropout(1, 0.5, 123, 2)
+    o = orc.Oracle(np.float64)
+    o.set_fusion(1)
+    try:
+        ref = o.step(d, params, tok, lens, img, lab, dr)
+    finally:
+        o.set_fusion(0)
+    base = o.step(d, params, tok, lens, img, lab, dr)
+    assert abs(ref["loss"] - base["loss"]) > 1e-6  # the variant really changes the model
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    ctx.set_fusion(1)
+    loss = ctx.step(tok, lens, img, lab, gdrop(pkg, dr))
+    assert abs(loss - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    bad = {k: e for k, e in segment_errors(orc, d, ctx.get_grads(), ref["grads"]).items() if e > 1e-3}
+    assert not bad, bad
+    ctx.close()
+
+
+def test_lr_scale(pkg, orc):
+    # gradients = join{enc*lr_scale, emb*lr_scale, mm}; clamp  (003_train_ae_based_wp.lua:344-345)
+    d = orc.make_dims(**KW)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    o = orc.Oracle(np.float32)
+    g = o.step(d, params, tok, lens, img, lab, None)["grads"]
+    s0, s1, s2 = orc.layout(d)["_segments"]
+    scale = np.concatenate([np.full(s0, 0.1, np.float32), np.full(s1, 0.1, np.float32), np.ones(s2, np.float32)])
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    ctx.set_grad_scales([0.1, 0.1, 1.0])
+    ctx.step(tok, lens, img, lab, None)
+    assert relmax(ctx.get_grads(), g * scale) < 1e-4
+    ctx.rmsprop_update(3e-4, 0.99, 1e-8, 0.0, 10.0)
+    x, m, gs = params.copy(), np.zeros_like(params), (g * scale).astype(np.float32)
+    o.rmsprop(x, gs, m, 3e-4, 0.99, 1e-8, 0.0, 10.0)
+    assert relmax(ctx.get_params(), x) < 1e-5
+    ctx.close()
+
+
+def test_two_block_feature_norm(pkg, orc):
+    # early fusion: [0,n) and [n,I) normalised separately (003_train_ae_based_ef.lua:115-119)
+    d = orc.make_dims(**{**KW, "I": 48})
+    params = orc.synth_params(d)
+    tok, lens, _, lab = orc.synth_batch(d, full_length=False)
+    rng = np.random.default_rng(2)
+    feats = np.abs(rng.standard_normal((20, d.I))).astype(np.float32)
+    img_pos = rng.integers(1, 21, d.B).astype(np.int32)
+    n = 16
+    fn = feats.copy()
+    fn[:, :n] /= np.sqrt((fn[:, :n] ** 2).sum(1, keepdims=True))
+    fn[:, n:] /= np.sqrt((fn[:, n:] ** 2).sum(1, keepdims=True))
+    tr = pkg.trainer.VQATrainer(gdims(pkg, d), 0, dropout=False)
+    tr.set_params(params)
+    tr.load_dataset(tok, lens, img_pos, lab, feats, img_norm=n)
+    q = np.arange(d.B, dtype=np.int64)
+    la = tr.ctx.step_indices(q, None)
+    ref = orc.Oracle(np.float64).step(d, params, tok, lens, fn[img_pos - 1], lab, None)
+    assert abs(la - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    tr.close()
+
+
+def test_late_fusion_and_results_json(pkg):
+    a = np.array([[0.1, 0.9], [0.6, 0.4]])
+    b = np.array([[0.8, 0.1], [0.2, 0.3]])
+    s = pkg.trainer.late_fusion(a, b, 1.0, 2.0)
+    assert s.argmax(1).tolist() == [0, 0]
+    r = pkg.trainer.results_json([11, 12], [2, 1], {"1": "yes", "2": "no"})
+    assert r == [{"question_id": 11, "answer": "no"}, {"question_id": 12, "answer": "yes"}]
