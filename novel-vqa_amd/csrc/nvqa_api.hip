@@ -91,7 +91,8 @@ static void prof_collect(nvqa_ctx *c)
 typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgMed;
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
-typedef Cfg<16, 32, 128, 32, 2, 2, 2, 2> CfgLstmFwd; // 8 waves: 2 K-groups x (2x2) tiles of 16 rows x 16 units x 4 gates
+typedef Cfg<16, 64, 64, 64, 4, 1, 2, 1> CfgLstmFwd; // 8 waves: 2 K-groups x 4 row tiles of 16 rows x 16 units x 4 gates (tools/kbench4: 37.5 vs 44.3 us per level)
+typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/kbench2: 34.2 vs 38.9 us per level for the 32x32x2 form)
 typedef Cfg<16, 32, 32, 128, 2, 2, 4, 2> CfgLstmBwd; // 16 waves: 4 K-groups x (2x2) tiles of 16x16
 
 template <int AM, int BMo, class Epi>
@@ -465,9 +466,9 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
         const int in = d.E;
         ProfScope ps(c, PF_GEMM_I2H, 2.0 * TB * 4 * R * in, ((double)TB * (in + 4 * R) + 4.0 * R * in) * 4);
         GemmArgs g = mkargs(c->X0, in, c->P + c->lo.w_i2h[0], in, TB, 4 * R, in);
-        // K-contiguous x K-contiguous: the 128x64 tile with the 2-deep pipeline measured 112 TF vs 101 TF
-        // for 128x128 (tools/kbench3)
-        NVQA_HIP((launch_gemm<Cfg<32, 128, 64, 32, 2, 2, 1, 2>, A_KC, B_KC, false, EpiBias2>(
+        // K-contiguous x K-contiguous: 64x64 tiles, 16x16x4 MFMA, 2 K-groups measured 119 TF vs 99 TF for
+        // the 128x128 32x32x2 form (tools/kbench3)
+        NVQA_HIP((launch_gemm<Cfg<16, 64, 64, 32, 2, 2, 2, 1>, A_KC, B_KC, false, EpiBias2>(
             c->s, g, EpiBias2{c->Gt[0], 4 * R, c->P + c->lo.b_i2h[0], c->P + c->lo.b_h2h[0]})));
     }
     // Wavefront over (layer, step): layer l at step t needs layer l at t-1 and layer l-1 at t, so
@@ -570,7 +571,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
         if (np > 0) {
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z;
-            NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
+            NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
         {
             ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nf * slab * (2.0 * NVQA_BWD_Z + 14) * 4);

@@ -47,14 +47,17 @@ int main()
     R_("   no mfma", A_KC, B_KC, 32, 128, 128, 32, 2, 2, 1, 1, 2)
     R_("   no epilogue", A_KC, B_KC, 32, 128, 128, 32, 2, 2, 1, 1, 4)
     R_("   no loads no epilogue", A_KC, B_KC, 32, 128, 128, 32, 2, 2, 1, 1, 5)
-    R_("KC/KC 128x128x32 DMA", A_KC, B_KC, 32, 128, 128, 32, 2, 2, 1, 1, 0, 1)
-    R_("KC/KC 128x128x64 DMA", A_KC, B_KC, 32, 128, 128, 64, 2, 2, 1, 1, 0, 1)
-    R_("KC/KC 128x64x32 DMA", A_KC, B_KC, 32, 128, 64, 32, 2, 2, 1, 1, 0, 1)
-    R_("KC/KC 128x64x64 DMA", A_KC, B_KC, 32, 128, 64, 64, 2, 2, 1, 1, 0, 1)
-    R_("KC/KC 256x128x32 DMA (8 waves)", A_KC, B_KC, 32, 256, 128, 32, 4, 2, 1, 1, 0, 1)
-    R_("KC/NC 128x128x32 DMA", A_KC, B_NC, 32, 128, 128, 32, 2, 2, 1, 1, 0, 1)
-    R_("MC/NC 128x128x32 DMA", A_MC, B_NC, 32, 128, 128, 32, 2, 2, 1, 1, 0, 1)
-    R_("MC/NC 128x128x64 DMA", A_MC, B_NC, 32, 128, 128, 64, 2, 2, 1, 1, 0, 1)
+    R_("KC/KC 128x128x32 mf16 wk2 pf1 (8 waves)", A_KC, B_KC, 16, 128, 128, 32, 2, 2, 2, 1, 0)
+    R_("KC/KC 128x128x32 mf16 4x2 pf1 (8 waves)", A_KC, B_KC, 16, 128, 128, 32, 4, 2, 1, 1, 0)
+    R_("KC/KC 128x128x32 mf16 4x4 pf1 (16 waves)", A_KC, B_KC, 16, 128, 128, 32, 4, 4, 1, 1, 0)
+    R_("KC/KC 128x64x32 mf16 wk2 pf1 (8 waves)", A_KC, B_KC, 16, 128, 64, 32, 2, 2, 2, 1, 0)
+    R_("KC/KC 128x64x32 mf16 4x2 pf1 (8 waves)", A_KC, B_KC, 16, 128, 64, 32, 4, 2, 1, 1, 0)
+    R_("KC/KC 64x64x32 mf16 wk2 pf1 (8 waves)", A_KC, B_KC, 16, 64, 64, 32, 2, 2, 2, 1, 0)
+    R_("KC/NC 128x128x32 mf16 wk2 pf1 (8 waves)", A_KC, B_NC, 16, 128, 128, 32, 2, 2, 2, 1, 0)
+    R_("KC/NC 128x128x32 mf16 4x2 pf1 (8 waves)", A_KC, B_NC, 16, 128, 128, 32, 4, 2, 1, 1, 0)
+    R_("MC/NC 128x128x32 mf16 wk2 pf1 (8 waves)", A_MC, B_NC, 16, 128, 128, 32, 2, 2, 2, 1, 0)
+    R_("MC/NC 128x128x32 mf16 4x2 pf1 (8 waves)", A_MC, B_NC, 16, 128, 128, 32, 4, 2, 1, 1, 0)
+    R_("MC/NC 128x128x32 mf32 wk2 pf1 (8 waves)", A_MC, B_NC, 32, 128, 128, 32, 2, 2, 2, 1, 0)
     R_("KC/KC 128x128x32 pf2", A_KC, B_KC, 32, 128, 128, 32, 2, 2, 1, 2, 0)
     R_("KC/KC 128x128x64 pf1", A_KC, B_KC, 32, 128, 128, 64, 2, 2, 1, 1, 0)
     R_("KC/KC 128x128x64 wk2 pf1 (8 waves)", A_KC, B_KC, 32, 128, 128, 64, 2, 2, 2, 1, 0)
