@@ -34,11 +34,7 @@
 #define NVQA_SITE_V 3u
 #define NVQA_SITE_Z 4u
 
-#if defined(__HIPCC__)
 NVQA_HD uint32_t nvqa_hash32(uint64_t seed, uint64_t step, uint32_t site, uint64_t idx)
-#else
-NVQA_HD uint32_t nvqa_hash32(uint64_t seed, uint64_t step, uint32_t site, uint64_t idx)
-#endif
 {
     uint64_t x = seed ^ (0x9E3779B97F4A7C15ULL * (step + 1ULL)) ^ ((uint64_t)site << 56);
     x += idx * 0xD1342543DE82EF95ULL;

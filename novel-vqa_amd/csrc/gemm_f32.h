@@ -16,16 +16,20 @@
 //   A_IM2COL: implicit im2col of an NHWC tensor (3x3 conv), K-contiguous like A_KC
 //   B_KC: B stored [N][K]  (k contiguous)     Torch nn.Linear weight [out][in] in forward
 //   B_NC: B stored [K][N]  (n contiguous)     the same weight in dgrad, activations in wgrad
-// LDS images are k-major ([BK][BM+pad]) so that a wave's MFMA operand read is 32 (or 16)
-// consecutive floats per k: conflict-free ds_read_b32.  K-contiguous sources are transposed
-// on the LDS write (pad chosen so the 4 scalar writes of a float4 hit distinct banks).
+// LDS images: K-contiguous operands are stored [rows][BK] with the 16-byte chunk index XOR-swizzled
+// by the row (conflict-free ds_read_b128 for the hardware's lane groups); one such read feeds 4
+// MFMAs, with the k order permuted identically for A and B: k(q, w, h) = QK*q + 4*h + w (h = lane
+// group, w = 0..3).  M/N-contiguous operands are stored k-major [BK][rows + 4] and read with
+// ds_read_b32.  Either way the global -> LDS copy is float4 in, float4 out: no transposing writes.
 //
-// Pipeline (PF = 2): two LDS buffers and two register tile sets; the global loads of tiles
-// t+1 and t+2 are in flight while tile t is multiplied, one barrier per tile.  The small
-// per-step LSTM products are latency-bound (one workgroup per CU, operands in L2), so what
-// matters is bytes in flight per CU, not MFMA scheduling.  WK > 1 splits each K-tile over
-// WK wave groups (more waves per SIMD to hide LDS/MFMA latency) and sums the partial
-// accumulators through LDS in a fixed order before the epilogue.
+// Pipeline: register-staged prefetch (PF = 1: next tile in flight while the current one is
+// multiplied, single LDS buffer; PF = 2: two tiles in flight, two LDS buffers, one barrier per
+// tile), fragment reads software-pipelined one q step ahead of the MFMAs.  Cfg::DMA selects a
+// direct global -> LDS variant (global_load_lds_dwordx4, swizzle on the source address); it is
+// bit-identical and measured equal or slower, so it is off.  WK > 1 splits each K-tile over WK wave
+// groups (more waves per SIMD) and sums the partial accumulators through LDS in a fixed order; the
+// epilogue is then spread over the groups.  blockIdx.z selects a K slice (split-K into slabs) or,
+// in gemm_f32_multi_kernel, one of several same-shape problems.
 //
 // GATES mode (fused LSTM cell): N indexes hidden units; the block's B tile holds the
 // rows {g*R + u} of the [4R][K] weight for its units u and all 4 gates g, and each lane

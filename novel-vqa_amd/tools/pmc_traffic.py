@@ -19,7 +19,7 @@ GROUPS = [
     ("lstm_step_bwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiStore" in n),
     ("lstm_bwd_finish", lambda n: "k_lstm_bwd_finish" in n),
     ("gemm_wgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n),
-    ("gemm_i2h_fwd", lambda n: "gemm_f32_kernel" in n and "EpiBias2" in n and "128, 64" in n),
+    ("gemm_i2h_fwd", lambda n: "gemm_f32_kernel" in n and "EpiBias2" in n and "Cfg<16, 64, 64, 32, 2, 2, 2, 1" in n),
     ("gemm_dgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 0, 1, false" in n and "EpiStore" in n),
     ("rmsprop", lambda n: "k_rmsprop" in n),
     ("emb_bwd", lambda n: "k_emb_bwd" in n),
