@@ -43,10 +43,13 @@ def flops_per_qa(w):
     return 3 * fwd - 2 * C * I, fwd
 
 
-def synth_dataset(w, seed):
+def synth_dataset(w, seed, ragged=False):
     rng = np.random.default_rng(seed)
     q = rng.integers(1, w["V"] + 1, (N_QUESTIONS, w["T"]), dtype=np.int32)  # all lengths = T
     lens = np.full(N_QUESTIONS, w["T"], np.int32)
+    if ragged:  # secondary case: lengths ~ U{3..T}, right-aligned, 0 = left padding
+        lens = rng.integers(3, w["T"] + 1, N_QUESTIONS).astype(np.int32)
+        q[np.arange(w["T"])[None, :] < (w["T"] - lens)[:, None]] = 0
     img_pos = rng.integers(1, N_IMAGES + 1, N_QUESTIONS, dtype=np.int32)
     ans = rng.integers(1, w["A"] + 1, N_QUESTIONS, dtype=np.int32)
     feats = np.abs(rng.standard_normal((N_IMAGES, w["I"]), dtype=np.float32))  # normalised on device
@@ -79,6 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--ragged", action="store_true", help="secondary case: question lengths ~ U{3..26}")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +106,7 @@ def main():
     tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123)
     tr.init_params()  # same on every rank (counter-based)
     tr.rng = np.random.default_rng(123 + 1000 * rank)  # each rank draws its own sample ids
-    tr.load_dataset(*synth_dataset(w, 123), img_norm=True)
+    tr.load_dataset(*synth_dataset(w, 123, args.ragged), img_norm=True)
     if world > 1:
         ids = [tr.ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -140,7 +144,7 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "arch1 002_train_baseline: V=14773 E=200 R=512 L=2 I=4096 C=1024 A=1000, "
-                               "all lengths 26, dropout 0.5 on, HBM-resident dataset, RMSprop",
+                               + ("lengths U{3..26}" if args.ragged else "all lengths 26") + ", dropout 0.5 on, HBM-resident dataset, RMSprop",
                    "global_batch": w["B"] * world, "seq_len": w["T"], "parallelism": f"dp{world}"},
         "flop_per_qa": fl_qa,
         "step_mfma_frac": round(value * fl_qa / (world * FP32_MFMA_PEAK_TFLOPS * 1e12), 4),

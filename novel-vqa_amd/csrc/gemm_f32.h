@@ -65,6 +65,13 @@ struct GemmArgs {
     // A_IM2COL: A is an NHWC activation [n][cH][cW][cC]; row m = output pixel (n, y, x) of a 3x3,
     // stride-1, pad-1 convolution, k = (ky*3 + kx)*cC + ci (cC % 4 == 0): implicit GEMM, no im2col buffer
     int cH, cW, cC;
+    // Ragged time-batched operands: rows come in groups of seg_rows (= B, one group per LSTM step) of
+    // which only the first seg_limits[group] are active (the rest are zero padding: questions that
+    // have not started yet, misc/RNNUtils.lua:136-145).  mseg: the M rows of A are grouped -> inactive
+    // row tiles are skipped altogether (their outputs are never read).  kseg: the K rows of an
+    // A_MC / B_NC product are grouped -> all-zero K-tiles are skipped.
+    const int *mseg_limits, *kseg_limits;
+    int seg_rows;
 };
 
 template <int MF> struct AccT;
@@ -162,6 +169,9 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     const int kend = min(g.K, kbeg + g.kslice);
     const int mlim = g.mlimit ? min(g.M, *g.mlimit) : g.M;
     const bool active = m0 < mlim;
+    if (g.mseg_limits && g.seg_rows % BM == 0) { // block-uniform, before any barrier
+        if (m0 % g.seg_rows >= g.mseg_limits[m0 / g.seg_rows]) return;
+    }
 
     typename AccT<MF>::type acc[NTM][NTN];
 #pragma unroll
@@ -205,7 +215,20 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     }
 
     // tile index -> (segment, k range)
-    const int nk1 = active && kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    const bool kskip = SEG == 0 && g.kseg_limits != nullptr && g.seg_rows % BK == 0 && kbeg % BK == 0;
+    int nk1 = active && kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    // kseg: count only the K-tiles that hold active rows; kit_* walks them in order (load_tiles is
+    // called with kt = 0, 1, 2, ... exactly once each)
+    int kit_seg = 0, kit_next = 0, kit_end = 0;
+    if (kskip && nk1 > 0) {
+        nk1 = 0;
+        const int s_lo = kbeg / g.seg_rows, s_hi = (kend - 1) / g.seg_rows;
+        for (int sgm = s_lo; sgm <= s_hi; ++sgm) {
+            const int lo = max(sgm * g.seg_rows, kbeg), hi = min(sgm * g.seg_rows + g.kseg_limits[sgm], kend);
+            if (hi > lo) nk1 += (hi - lo + BK - 1) / BK;
+        }
+        kit_seg = s_lo - 1; // the iterator advances into the first non-empty group on first use
+    }
     const int nk2 = SEG > 0 && active ? (g.K2 + BK - 1) / BK : 0;
     const int nk = nk1 + nk2;
 
@@ -278,8 +301,17 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
             return;
         }
         const bool s2 = SEG > 0 && kt >= nk1;
-        const int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
+        int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
         const int kend = s2 ? g.K2 : min(g.K, kbeg + g.kslice);
+        if (kskip) {
+            while (kit_next >= kit_end) {
+                ++kit_seg;
+                kit_next = max(kit_seg * g.seg_rows, kbeg);
+                kit_end = min(kit_seg * g.seg_rows + g.kseg_limits[kit_seg], kend);
+            }
+            k0 = kit_next;
+            kit_next += BK;
+        }
         const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {

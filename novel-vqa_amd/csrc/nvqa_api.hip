@@ -440,6 +440,7 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
     {
         ProfScope ps(c, PF_GEMM_WGRAD, 2.0 * M * N * K, ((double)K * (M + N) + (double)ks * M * N) * 4, st);
         GemmArgs g = mkargs(A, lda, Bm, ldb, M, N, K, kslice);
+        g.kseg_limits = c->nrows; g.seg_rows = c->d.B; // K rows = (step, sorted row): skip the zero padding
         if (ks == 1) {
             NVQA_TRY((gemm_big<A_MC, B_NC>(c, g, EpiStore{dW, N, 0}, st)));
             return 0;
@@ -466,6 +467,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
         const int in = d.E;
         ProfScope ps(c, PF_GEMM_I2H, 2.0 * TB * 4 * R * in, ((double)TB * (in + 4 * R) + 4.0 * R * in) * 4);
         GemmArgs g = mkargs(c->X0, in, c->P + c->lo.w_i2h[0], in, TB, 4 * R, in);
+        g.mseg_limits = c->nrows; g.seg_rows = B; // rows of not-yet-started questions are skipped
         // K-contiguous x K-contiguous: 64x64 tiles, 16x16x4 MFMA, 2 K-groups measured 119 TF vs 99 TF for
         // the 128x128 32x32x2 form (tools/kbench3)
         NVQA_HIP((launch_gemm<Cfg<16, 64, 64, 32, 2, 2, 2, 1>, A_KC, B_KC, false, EpiBias2>(
@@ -601,6 +603,7 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
     const int R = d.R, TB = c->TS * d.B;
     ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
     GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
+    g.mseg_limits = c->nrows; g.seg_rows = d.B;
     NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiStore{dX0, d.E, 0})));
     return 0;
 }
