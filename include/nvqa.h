@@ -168,6 +168,14 @@ int nvqa_vgg16_fc7(nvqa_vgg *vgg, const float *images, int n, float *feats_out);
  * x255, RGB->BGR, mean subtraction.  out: n x 3 x hw x hw. */
 int nvqa_vgg16_preprocess(nvqa_vgg *vgg, const float *rgb, int n, int H, int W, float *out);
 
+/* The extractor run on the fly in front of the training step (BASELINE config "end-to-end"):
+ * images [B x 3 x hw x hw] as loadim returns them -> fc7 -> row L2 norm (002_train_baseline.lua:117-121)
+ * -> the JdJ body of nvqa_step.  The extractor's feature width must equal dims.I; the features
+ * never leave the device. */
+int nvqa_step_images(nvqa_ctx *ctx, nvqa_vgg *vgg, const float *images, const int32_t *tokens,
+                     const int32_t *lengths, const int32_t *labels, const nvqa_dropout *dropout,
+                     float *loss_out);
+
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event timing of kernel groups on the stream they are launched on.
  * enable=1 brackets every launch with events (slows the step; bench.py uses a

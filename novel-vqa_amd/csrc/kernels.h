@@ -64,6 +64,28 @@ __global__ void k_l2norm_rows(float *F, int64_t n, int ld, int col0, int I)
     }
 }
 
+// fc7 features -> row L2 norm (002_train_baseline.lua:117-121) -> the step's image-feature buffer
+// (BASELINE config 5: the extractor fused in front of the training step).  One wave per row.
+__global__ void k_l2norm_copy(const float *src, int n, int I, float *dst)
+{
+    const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float4 *p = reinterpret_cast<const float4 *>(src + (size_t)row * I);
+    float4 *q = reinterpret_cast<float4 *>(dst + (size_t)row * I);
+    float s = 0.f;
+    for (int i = lane; i < I / 4; i += 64) {
+        const float4 v = p[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = sqrtf(wave_sum(s));
+    for (int i = lane; i < I / 4; i += 64) {
+        float4 v = p[i];
+        v.x /= s; v.y /= s; v.z /= s; v.w /= s;
+        q[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // sort_encoding_onehot_right_align (misc/RNNUtils.lua:84-124) without the one-hot:
 // stable descending counting sort of the lengths, inverse permutation, and the number of

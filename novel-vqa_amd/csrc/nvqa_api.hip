@@ -867,6 +867,34 @@ extern "C" int nvqa_step(nvqa_ctx *c, const int32_t *tokens, const int32_t *leng
     return run_step(c, dropout, loss_out);
 }
 
+// BASELINE.json configs[4]: the VGG-16 fc7 extractor run on the fly in front of the arch1 step
+// (001_prepro_img_vgg.lua:101-113 + 002_train_baseline.lua:117-121 + JdJ).  images [B x 3 x hw x hw] as loadim
+// returns them; the extractor's feature width must equal dims.I.
+struct nvqa_vgg;
+int nvqa_vgg_forward_device(nvqa_vgg *v, const float *images, int n, const float **feats_dev, int *F, hipStream_t *stream);
+
+extern "C" int nvqa_step_images(nvqa_ctx *c, nvqa_vgg *vgg, const float *images, const int32_t *tokens,
+                                const int32_t *lengths, const int32_t *labels, const nvqa_dropout *dropout,
+                                float *loss_out)
+{
+    if (!c || !vgg || !images || !labels) { set_error("NULL argument"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    // tokens / lengths / labels go through the usual validated upload; the image slot gets a dummy
+    std::vector<float> zero((size_t)c->d.B * c->d.I, 0.f);
+    NVQA_TRY(upload_batch(c, c->d.B, tokens, lengths, zero.data(), labels));
+    const float *feats = nullptr;
+    int F = 0;
+    hipStream_t vs = nullptr;
+    NVQA_TRY(nvqa_vgg_forward_device(vgg, images, c->d.B, &feats, &F, &vs));
+    if (F != c->d.I) { set_error("extractor feature width %d != dims.I %d", F, c->d.I); return -1; }
+    // the step's stream waits for the extractor's stream, then normalises straight into the batch buffer
+    NVQA_HIP(hipEventRecord(c->evStart, vs));
+    NVQA_HIP(hipStreamWaitEvent(c->s, c->evStart, 0));
+    hipLaunchKernelGGL(k_l2norm_copy, dim3((c->d.B + 3) / 4), dim3(256), 0, c->s, feats, c->d.B, c->d.I, c->img);
+    NVQA_HIP(hipGetLastError());
+    return run_step(c, dropout, loss_out);
+}
+
 extern "C" int nvqa_forward(nvqa_ctx *c, int32_t n, const int32_t *tokens, const int32_t *lengths,
                             const float *img, float *scores_out, int32_t *argmax_out)
 {

@@ -256,10 +256,10 @@ static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, c
     return 0;
 }
 
-// images: n x 3 x hw x hw, already preprocessed (BGR, mean-subtracted: loadim's output).
-extern "C" int nvqa_vgg16_fc7(nvqa_vgg *v, const float *images, int n, float *feats_out)
+// forward of n host images; the post-ReLU fc7 features stay on the device in v->fc7o [n x F]
+static int vgg_forward(nvqa_vgg *v, const float *images, int n)
 {
-    if (!v || !images || !feats_out) { set_error("NULL argument"); return -1; }
+    if (!v || !images) { set_error("NULL argument"); return -1; }
     if (!v->have_weights) { set_error("nvqa_vgg16_fc7 before nvqa_vgg16_set_weights"); return -1; }
     if (n < 1 || n > v->max_batch) { set_error("n=%d outside 1..%d", n, v->max_batch); return -1; }
     NVQA_HIP(hipSetDevice(v->device));
@@ -297,8 +297,26 @@ extern "C" int nvqa_vgg16_fc7(nvqa_vgg *v, const float *images, int n, float *fe
     const int c5p = (v->c5 + 3) / 4 * 4;
     NVQA_TRY(fc_layer(v, cur, n, v->s5 * v->s5 * c5p, v->Wf[0], v->bf[0], v->fc6o)); // fc6 + ReLU (Dropout = identity)
     NVQA_TRY(fc_layer(v, v->fc6o, n, v->F, v->Wf[1], v->bf[1], v->fc7o));              // fc7 + ReLU -> module 38
+    return 0;
+}
+
+// images: n x 3 x hw x hw, already preprocessed (BGR, mean-subtracted: loadim's output).
+extern "C" int nvqa_vgg16_fc7(nvqa_vgg *v, const float *images, int n, float *feats_out)
+{
+    if (!feats_out) { set_error("NULL argument"); return -1; }
+    NVQA_TRY(vgg_forward(v, images, n));
     NVQA_HIP(hipMemcpyAsync(feats_out, v->fc7o, (size_t)n * v->F * 4, hipMemcpyDeviceToHost, v->s));
     NVQA_HIP(hipStreamSynchronize(v->s));
+    return 0;
+}
+
+// used by nvqa_step_images (nvqa_api.hip): run the extractor, leave the features on the device
+int nvqa_vgg_forward_device(nvqa_vgg *v, const float *images, int n, const float **feats_dev, int *F, hipStream_t *stream)
+{
+    NVQA_TRY(vgg_forward(v, images, n));
+    *feats_dev = v->fc7o;
+    *F = v->F;
+    *stream = v->s;
     return 0;
 }
 

@@ -64,6 +64,7 @@ SYMBOLS = {
     "nvqa_vgg16_set_weights": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_vgg16_fc7": (ctypes.c_int, [_vp, _f32p, ctypes.c_int, _f32p]),
     "nvqa_vgg16_preprocess": (ctypes.c_int, [_vp, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p]),
+    "nvqa_step_images": (ctypes.c_int, [_vp, _vp, _f32p, _i32p, _i32p, _i32p, ctypes.POINTER(Dropout), _f32p]),
     "nvqa_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_profile_reset": (ctypes.c_int, [_vp]),
     "nvqa_profile_count": (ctypes.c_int, [_vp]),
@@ -177,6 +178,19 @@ class Context:
         self._check(self.lib.nvqa_step_indices(self._h, q.ctypes.data_as(_i64p), dr,
                                                ctypes.byref(loss) if want_loss else None))
         return float(loss.value) if want_loss else None
+
+    def step_images(self, vgg, images, tokens, lengths, labels, dropout=None):
+        """Extractor + training step in one call (features stay on the device)."""
+        d = self.dims
+        images = np.ascontiguousarray(images, np.float32)
+        tokens = np.ascontiguousarray(tokens, np.int32).reshape(d.B, d.T)
+        lengths = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        labels = np.ascontiguousarray(labels, np.int32)
+        loss = ctypes.c_float(0)
+        dr = ctypes.byref(dropout) if dropout is not None else None
+        self._check(self.lib.nvqa_step_images(self._h, vgg._h, _f32(images), _i32(tokens), _i32(lengths),
+                                              _i32(labels), dr, ctypes.byref(loss)))
+        return float(loss.value)
 
     def get_loss(self):
         loss = ctypes.c_float(0)
