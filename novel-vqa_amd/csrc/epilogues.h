@@ -32,19 +32,6 @@ struct EpiStore {
     }
 };
 
-// C[m][n] += v : time-chunked weight gradients accumulate in launch order on one stream
-// (nn.Linear accGradParameters summed over the LSTM clones, 002_train_baseline.lua:323-326)
-struct EpiAccum {
-    float *C;
-    int ldc;
-    int first; // 1: overwrite (first chunk), 0: accumulate
-    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
-    {
-        float *p = C + (size_t)m * ldc + n;
-        *p = first ? v : *p + v;
-    }
-};
-
 // nn.Linear bias add (two biases: b_i2h + b_h2h of misc/LSTM.lua:41-43 folded into the
 // time-batched i2h product)
 struct EpiBias2 {
@@ -128,20 +115,6 @@ struct EpiHead2 {
     }
 };
 
-// d(input of layer l) -> inter-layer Dropout backward (misc/LSTM.lua:37); rows are (t, r)
-struct EpiDU {
-    float *out; // [T*B][R]
-    const int *sort_idx;
-    int B, T, R, lm1; // lm1 = layer index - 1 (0-based layer l >= 1 -> l-1)
-    Drop dr;
-    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
-    {
-        const int t = m / B, r = m % B;
-        const uint64_t idx = ((((uint64_t)lm1) * B + sort_idx[r]) * T + t) * R + n;
-        out[(size_t)m * R + n] = dr.scale(NVQA_SITE_LSTM, idx) * v;
-    }
-};
-
 // Fused LSTM cell forward (misc/LSTM.lua:43-59): a[4] = W_h2h h_{t-1} for gates (i,f,o,g);
 // gx holds W_i2h x_t + b_i2h + b_h2h on entry and the ACTIVATED gates on exit (kept for BPTT).
 // Rows >= *nrows have not started yet and keep a zero state (misc/RNNUtils.lua:136-145).
@@ -204,7 +177,7 @@ struct EpiLstmBwd {
     float *gates;              // [B][4R] of step s (in: i,f,o,g ; out: da)
     const float *c_prev, *c;   // [B][R] cell before / after step s
     float *dc;                 // [B][R] carried cell gradient (in: dL/dc_s from s+1, out: dL/dc_{s-1})
-    const float *dh_ext, *dh_ext2; // optional extra dL/dh_s terms (upper layer, head)
+    const float *dh_ext, *dh_ext2; // optional extra dL/dh_s terms (dh_ext unused now; dh_ext2 = head)
     const int *tlast;              // optional: dh_ext2 enters only at step *tlast (arch2: tmax-1)
     const int *nrows;
     int R;

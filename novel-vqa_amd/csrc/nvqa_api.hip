@@ -86,14 +86,13 @@ static void prof_collect(nvqa_ctx *c)
 // BIG : 128x128x32 block, 4 waves of 64x64 (2x2 MFMA 32x32x2 tiles)  -- time-batched products
 // MED : 64x64x32 block, 4 waves of 32x32                              -- M = B products of the head
 // LSTM forward step : 32 rows x 32 units x 4 gates, MFMA 16x16x4, fused cell
-// LSTM backward step: 32x32, MFMA 16x16x4, fused cell backward
+// BPTT level      : 64x64x32 split-K products into slabs + k_lstm_bwd_finish
 //                 MF   BM   BN   BK  WM WN WK PF
 typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgMed;
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
 typedef Cfg<16, 64, 64, 64, 4, 1, 2, 1> CfgLstmFwd; // 8 waves: 2 K-groups x 4 row tiles of 16 rows x 16 units x 4 gates (tools/kbench4: 37.5 vs 44.3 us per level)
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/kbench2: 34.2 vs 38.9 us per level for the 32x32x2 form)
-typedef Cfg<16, 32, 32, 128, 2, 2, 4, 2> CfgLstmBwd; // 16 waves: 4 K-groups x (2x2) tiles of 16x16
 
 template <int AM, int BMo, class Epi>
 static int gemm_big(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
@@ -176,28 +175,14 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     const nvqa_dims &d = c->d;
     c->TS = d.arch == NVQA_ARCH1 ? d.T : d.T + 2;
     const size_t B = d.B, R = d.R, E = d.E, L = d.L, TS = c->TS, TB = TS * B;
-    {   // the recurrence chains run at the highest priority, the bulk weight-gradient GEMMs at the lowest
+    {   // one compute stream (the whole step is a single dependency chain of chip-filling launches) and
+        // one communication stream for the data-parallel all-reduce buckets
         int least = 0, greatest = 0;
         NVQA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         NVQA_HIP(hipStreamCreateWithPriority(&c->s, hipStreamNonBlocking, greatest));
-        for (int l = 1; l < d.L; ++l) NVQA_HIP(hipStreamCreateWithPriority(&c->sl[l], hipStreamNonBlocking, greatest));
-        NVQA_HIP(hipStreamCreateWithPriority(&c->sb, hipStreamNonBlocking, least));
-        NVQA_HIP(hipStreamCreateWithPriority(&c->sb2, hipStreamNonBlocking, least));
         NVQA_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, greatest));
         for (int i = 0; i < 3; ++i) NVQA_HIP(hipEventCreateWithFlags(&c->evSeg[i], hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evComm, hipEventDisableTiming));
-        c->sl[0] = c->s;
-        for (int l = 0; l < d.L; ++l) {
-            c->evF[l].resize(c->TS);
-            c->evB[l].resize(c->TS);
-            for (int t = 0; t < c->TS; ++t) {
-                NVQA_HIP(hipEventCreateWithFlags(&c->evF[l][t], hipEventDisableTiming));
-                NVQA_HIP(hipEventCreateWithFlags(&c->evB[l][t], hipEventDisableTiming));
-            }
-        }
-        NVQA_HIP(hipEventCreateWithFlags(&c->evHead, hipEventDisableTiming));
-        NVQA_HIP(hipEventCreateWithFlags(&c->evBulk, hipEventDisableTiming));
-        NVQA_HIP(hipEventCreateWithFlags(&c->evBulk2, hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
     }
     NVQA_TRY(dalloc(&c->P, c->lo.total));
@@ -230,7 +215,6 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
             c->Cs[l] = c->Cs[0] + l * (TS + 1) * B * R;
         }
         if (l > 0) NVQA_TRY(dalloc(&c->U[l], TB * R));
-        if (l + 1 < L) NVQA_TRY(dalloc(&c->dHext[l], TB * R));
     }
     NVQA_TRY(dalloc(&c->dCT, L * B * R));
     NVQA_TRY(dalloc(&c->dHT, L * B * R));
@@ -252,7 +236,6 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     NVQA_TRY(dalloc(&c->colpart, 64 * widest));
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
-    NVQA_TRY(dalloc(&c->slabs2, c->slab_floats));
     NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * B * R));
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
@@ -270,7 +253,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     comm_destroy(c);
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
-                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->slabs2, c->chain_slabs,
+                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -279,21 +262,11 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
         if (l == 0 && c->Hs[l]) (void)hipFree(c->Hs[l]);
         if (l == 0 && c->Cs[l]) (void)hipFree(c->Cs[l]);
         if (c->U[l]) (void)hipFree(c->U[l]);
-        if (c->dHext[l]) (void)hipFree(c->dHext[l]);
     }
     if (c->h_loss) (void)hipHostFree(c->h_loss);
-    for (int l = 0; l < NVQA_MAX_LAYERS; ++l) {
-        for (hipEvent_t e : c->evF[l]) (void)hipEventDestroy(e);
-        for (hipEvent_t e : c->evB[l]) (void)hipEventDestroy(e);
-        if (l > 0 && c->sl[l]) (void)hipStreamDestroy(c->sl[l]);
-    }
-    for (hipEvent_t e : {c->evHead, c->evBulk, c->evBulk2, c->evStart})
+    for (hipEvent_t e : {c->evSeg[0], c->evSeg[1], c->evSeg[2], c->evComm, c->evStart})
         if (e) (void)hipEventDestroy(e);
-    if (c->sb) (void)hipStreamDestroy(c->sb);
-    if (c->sb2) (void)hipStreamDestroy(c->sb2);
     if (c->sc) (void)hipStreamDestroy(c->sc);
-    for (hipEvent_t e : {c->evSeg[0], c->evSeg[1], c->evSeg[2], c->evComm})
-        if (e) (void)hipEventDestroy(e);
     if (c->s) (void)hipStreamDestroy(c->s);
     delete c;
     return 0;

@@ -69,11 +69,8 @@ struct nvqa_ctx {
     nvqa_dims d;
     nvqa_layout lo;
     int device = 0;
-    hipStream_t s = nullptr;                     // main stream (also the layer-0 recurrence chain)
-    hipStream_t sl[NVQA_MAX_LAYERS] = {};        // recurrence chains of layers >= 1 (high priority)
-    hipStream_t sb = nullptr, sb2 = nullptr;     // bulk streams: time-chunked weight gradients (low priority)
-    std::vector<hipEvent_t> evF[NVQA_MAX_LAYERS], evB[NVQA_MAX_LAYERS]; // per layer, per step
-    hipEvent_t evHead = nullptr, evBulk = nullptr, evBulk2 = nullptr, evStart = nullptr;
+    hipStream_t s = nullptr;                     // compute stream
+    hipEvent_t evStart = nullptr;                // hand-off from the extractor's stream (nvqa_step_images)
     hipStream_t sc = nullptr;                    // communication stream (RCCL all-reduce buckets)
     hipEvent_t evSeg[3] = {}, evComm = nullptr;  // segment ready / exchange done
     int TS = 0; // recurrent steps: arch1 T, arch2 T+2
@@ -98,12 +95,11 @@ struct nvqa_ctx {
     float *Hs[NVQA_MAX_LAYERS] = {};           // [(TS+1)*B][R]
     float *Cs[NVQA_MAX_LAYERS] = {};           // [(TS+1)*B][R]
     float *U[NVQA_MAX_LAYERS] = {};            // [TS*B][R] Dropout(h of layer below), l >= 1
-    float *dHext[NVQA_MAX_LAYERS] = {};        // [TS*B][R] dL/dh from the layer above, l < L-1
     float *dCT = nullptr, *dHT = nullptr;      // [L][B][R] head -> final state gradients
     float *qd = nullptr, *vd = nullptr, *qc = nullptr, *ic = nullptr, *zd = nullptr;
     float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
     float *dqc = nullptr, *dic = nullptr;
-    float *colpart = nullptr, *slabs = nullptr, *slabs2 = nullptr;
+    float *colpart = nullptr, *slabs = nullptr;
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
