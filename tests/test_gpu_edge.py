@@ -1,0 +1,65 @@
+"""Edge shapes through the C ABI (the GEMM tiles are 64-128 wide; everything here is smaller than a
+tile, or degenerate): batch of one, one time step, one token per question, four LSTM layers,
+all-null arch2 questions, a short eval batch."""
+import numpy as np
+import pytest
+
+from util import gdims, gdrop, relmax, segment_errors
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(pkg, orc, d, tok, lens, img, lab, mode=1):
+    params = orc.synth_params(d)
+    dr = orc.Dropout(mode, 0.5, 123, 2)
+    ref = orc.Oracle(np.float64).step(d, params, tok, lens, img, lab, dr)
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    loss = ctx.step(tok, lens, img, lab, gdrop(pkg, dr))
+    assert abs(loss - ref["loss"]) <= 1e-5 * abs(ref["loss"]), (loss, ref["loss"])
+    bad = {k: e for k, e in segment_errors(orc, d, ctx.get_grads(), ref["grads"]).items()
+           if e > 1e-3 and np.abs(ref["grads"][orc.layout(d)[k][0]:sum(orc.layout(d)[k])]).max() > 1e-12}
+    assert not bad, bad
+    ctx.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(arch=1, B=1, T=5, V=9, E=8, R=8, L=2, I=8, C=8, A=4),
+    dict(arch=1, B=3, T=1, V=9, E=8, R=8, L=2, I=8, C=8, A=4),
+    dict(arch=1, B=70, T=4, V=9, E=4, R=4, L=4, I=4, C=4, A=4),
+    dict(arch=2, B=1, T=3, V=9, E=8, R=8, L=1, I=8, C=4, A=4),
+    dict(arch=2, B=5, T=4, V=9, E=8, R=12, L=4, I=8, C=4, A=8),
+])
+def test_small_and_deep(pkg, orc, kw):
+    d = orc.make_dims(**kw)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    _check(pkg, orc, d, tok, lens if d.arch == 1 else None, img, lab)
+
+
+def test_one_token_questions(pkg, orc):
+    d = orc.make_dims(arch=1, B=9, T=6, V=20, E=8, R=8, L=2, I=8, C=8, A=4)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    lens[:] = 1
+    tok[:, :-1] = 0
+    tok[:, -1] = np.arange(1, d.B + 1)
+    _check(pkg, orc, d, tok, lens, img, lab)
+
+
+def test_arch2_all_null_questions(pkg, orc):
+    # every sequence empty: the encoder sees the image and START only (tmax = 2)
+    d = orc.make_dims(arch=2, B=4, T=5, V=9, E=8, R=8, L=2, I=8, C=4, A=4)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    tok[:] = 0
+    _check(pkg, orc, d, tok, None, img, lab)
+
+
+def test_short_eval_batch(pkg, orc):
+    d = orc.make_dims(arch=1, B=16, T=6, V=20, E=8, R=8, L=2, I=8, C=8, A=4)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    ev = orc.Oracle(np.float64).step(d, params, tok, lens, img, lab, None, train=False)
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    scores, argmax = ctx.forward(tok[:5], lens[:5], img[:5])   # n < B rows (last batch of a split)
+    assert scores.shape == (5, d.A) and relmax(scores, ev["scores"][:5]) < 1e-4
+    ctx.close()
