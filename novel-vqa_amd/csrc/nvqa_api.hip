@@ -7,12 +7,14 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <vector>
 
 #include "gemm_f32.h"
+#include "gemm_ring.h"
 #include "kernels.h"
 #include "nvqa_ctx.h"
 
@@ -39,7 +41,8 @@ extern "C" const char *nvqa_last_error(void) { return g_err; }
 static const char *kProfNames[PF_COUNT] = {
     "assemble",      "emb_fwd",       "gemm_i2h_fwd", "lstm_step_fwd", "head_prep", "gemm_head_fwd",
     "softmax_ce",    "gemm_head_bwd", "lstm_step_bwd", "gemm_dgrad",   "gemm_wgrad", "reduce_slabs",
-    "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch", "lstm_bwd_finish"};
+    "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch", "lstm_bwd_finish",
+    "transpose_w"};
 
 struct ProfScope {
     nvqa_ctx *c;
@@ -237,6 +240,11 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
     NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * B * R));
+    {   // ring kernel: K-contiguous operands, K multiples of 32, whole 16-unit gate tiles
+        const char *env = getenv("NVQA_RING");
+        c->use_ring = !(env && env[0] == '0') && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
+        if (c->use_ring) NVQA_TRY(dalloc(&c->WT, (size_t)L * 2 * 4 * R * R));
+    }
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
     NVQA_HIP(hipStreamSynchronize(c->s));
@@ -253,7 +261,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     comm_destroy(c);
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
-                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs,
+                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -481,7 +489,10 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
             ++np;
         }
         ProfScope ps(c, PF_LSTM_FWD, flops, bytes);
-        NVQA_HIP((launch_gemm_multi<CfgLstmFwd, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
+        bool ring = c->use_ring;
+        for (int i = 0; i < np && ring; ++i) ring = ring_ok(ma.g[i], true);
+        if (ring) NVQA_HIP((launch_gemm_ring_multi<true, EpiLstmFwd, 1>(c->s, ma, np)));
+        else NVQA_HIP((launch_gemm_multi<CfgLstmFwd, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
     }
     return 0;
 }
@@ -495,6 +506,19 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
+    const bool ring = c->use_ring;
+    const size_t wt = (size_t)4 * R * R;
+    if (ring) { // W_h2h^l [4R][R] -> [R][4R], W_i2h^l (l >= 1) likewise: the level products become K-contiguous x K-contiguous
+        ProfScope ps(c, PF_TRANSPOSE, 0, (double)(2 * L - 1) * wt * 8);
+        for (int l = 0; l < L; ++l) {
+            hipLaunchKernelGGL(k_transpose, dim3(R / 32, 4 * R / 32), dim3(256), 0, c->s, c->P + c->lo.w_h2h[l], 4 * R, R,
+                               c->WT + ((size_t)l * 2 + 0) * wt);
+            if (l > 0)
+                hipLaunchKernelGGL(k_transpose, dim3(R / 32, 4 * R / 32), dim3(256), 0, c->s, c->P + c->lo.w_i2h[l], 4 * R, R,
+                                   c->WT + ((size_t)l * 2 + 1) * wt);
+        }
+        NVQA_HIP(hipGetLastError());
+    }
     for (int dg = 0; dg < TS + L - 1; ++dg) {
         // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j).
         // Products of the level: dG_{s+1} W_h2h (none at the last step) and, below the top layer,
@@ -529,12 +553,14 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
             if (!last) {
                 ma.g[np] = mkargs(c->Gt[l] + (size_t)(s + 1) * B * 4 * R, 4 * R, c->P + c->lo.w_h2h[l], R, B, R, 4 * R,
                                   4 * R / NVQA_BWD_Z, 0, c->nrows + s);
+                if (ring) { ma.g[np].B = c->WT + ((size_t)l * 2 + 0) * wt; ma.g[np].ldb = 4 * R; }
                 ma.e[np] = EpiStore{srec, R, slab};
                 ++np;
             }
             if (!top) {
                 ma.g[np] = mkargs(c->Gt[l + 1] + (size_t)s * B * 4 * R, 4 * R, c->P + c->lo.w_i2h[l + 1], R, B, R, 4 * R,
                                   4 * R / NVQA_BWD_Z, 0, c->nrows + s);
+                if (ring) { ma.g[np].B = c->WT + ((size_t)(l + 1) * 2 + 1) * wt; ma.g[np].ldb = 4 * R; }
                 ma.e[np] = EpiStore{sup, R, slab};
                 ++np;
             }
@@ -546,7 +572,8 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
         if (np > 0) {
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z;
-            NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
+            if (ring) NVQA_HIP((launch_gemm_ring_multi<false, EpiStore, 0>(c->s, ma, np)));
+            else NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
         {
             ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nf * slab * (2.0 * NVQA_BWD_Z + 14) * 4);

@@ -48,6 +48,7 @@ enum ProfId {
     PF_ALLREDUCE,
     PF_GATHER,
     PF_LSTM_BWD_FIN, // slab sum + fused cell backward of one BPTT level
+    PF_TRANSPOSE,    // W -> W^T copies for the BPTT level products (ring kernel wants K-contiguous operands)
     PF_COUNT
 };
 
@@ -101,6 +102,8 @@ struct nvqa_ctx {
     float *dqc = nullptr, *dic = nullptr;
     float *colpart = nullptr, *slabs = nullptr;
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
+    float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
+    bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
     float *h_loss = nullptr; // pinned
