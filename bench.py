@@ -17,6 +17,9 @@ import time
 
 import numpy as np
 
+# the CPU baseline (OpenMP oracle) runs on this job's share of the host: at most 16 threads per GPU
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -26,6 +29,7 @@ import __graft_entry__ as ge  # noqa: E402
 WORKLOAD = dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000)
 N_QUESTIONS, N_IMAGES = 65536, 8192
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 
 
 def flops_per_qa(w):
@@ -69,7 +73,7 @@ def cpu_baseline(w):
     t0 = time.perf_counter()
     o.step(d, params, tok, lens, img, lab, orc.Dropout(1, 0.5, 123, 0))
     dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0))
+    cores = min(int(os.environ["OMP_NUM_THREADS"]), len(os.sched_getaffinity(0)))  # threads the oracle actually used
     return {"value": round(w["B"] / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
             "sample": f"1 forward+backward of the same B={w['B']} batch (no optimiser step), "
                       f"OpenMP C restatement oracle/nvqa_oracle.c, {dt:.1f} s"}
@@ -83,6 +87,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="secondary case: question lengths ~ U{3..26}")
+    ap.add_argument("--bf16", action="store_true",
+                    help="secondary case: nvqa_set_precision(1), dense products on the bf16 matrix cores "
+                         "(operands rounded to bf16, f32 accumulate); the headline metric is the f32 run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +112,8 @@ def main():
     dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
     tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123)
     tr.init_params()  # same on every rank (counter-based)
+    if args.bf16:
+        tr.ctx.set_precision(1)
     tr.rng = np.random.default_rng(123 + 1000 * rank)  # each rank draws its own sample ids
     tr.load_dataset(*synth_dataset(w, 123, args.ragged), img_norm=True)
     if world > 1:
@@ -137,17 +146,18 @@ def main():
     loss = tr.ctx.get_loss()
 
     fl_qa, _ = flops_per_qa(w)
+    peak = BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS
     value = w["B"] * world * args.steps / dt
     out = {
         "metric": "QA-pairs/sec training step (batch 512, seq 26)", "value": round(value, 1),
         "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16 operands, f32 accumulate" if args.bf16 else "f32", "data": "synthetic",
         "config": {"workload": "arch1 002_train_baseline: V=14773 E=200 R=512 L=2 I=4096 C=1024 A=1000, "
                                + ("lengths U{3..26}" if args.ragged else "all lengths 26") + ", dropout 0.5 on, HBM-resident dataset, RMSprop",
                    "global_batch": w["B"] * world, "seq_len": w["T"], "parallelism": f"dp{world}"},
         "flop_per_qa": fl_qa,
-        "step_mfma_frac": round(value * fl_qa / (world * FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+        "step_mfma_frac": round(value * fl_qa / (world * peak * 1e12), 4),
         "final_loss": round(loss, 5),
     }
 
@@ -176,8 +186,8 @@ def main():
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None if args.bf16 else traffic,
                                "avg_launch_ms": round(avg_ms, 5),
                                "launches_per_step": pv["launches"] // nprof}
             out["kernel_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in prof.items()

@@ -128,6 +128,12 @@ int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float w
 /* askip = 1: netdef.AskipB fusion, output = qc + qc (*) ic (misc/netdef.lua:16-25,
  * 003_train_ae_based_wp.lua:151) instead of netdef.AxB.  arch1 only. */
 int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
+/* BASELINE config "arch2 ... bf16": bf16 = 1 runs every dense product of the step (forward, dgrad, wgrad)
+ * on the bf16 matrix cores: both operands rounded to bf16 (round-to-nearest-even) as they are read,
+ * products accumulated in f32.  Parameters, activations, gradients, the optimiser and everything at this
+ * ABI stay f32 (SURVEY.md 8b "numerics contract").  Default 0 = the reference's f32 arithmetic
+ * (torch.setdefaulttensortype('torch.FloatTensor'), 002_train_baseline.lua:54). */
+int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
 /* Per-segment gradient scale applied before the clamp: {lr_scale, lr_scale, 1} reproduces
  * -lr_scale of 003_train_ae_based_wp.lua:30,344. */
 int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);

@@ -91,14 +91,40 @@ __device__ __forceinline__ f32x4 mfma<16>(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 pack_bf16(const float4 &v)
+{
+    const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    const u32x2 r = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
+    return __builtin_bit_cast(s16x4, r);
+}
+template <int MF>
+__device__ __forceinline__ typename AccT<MF>::type mfma_bf16(s16x4 a, s16x4 b, typename AccT<MF>::type c);
+template <> __device__ __forceinline__ f32x16 mfma_bf16<32>(s16x4 a, s16x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma_bf16<16>(s16x4 a, s16x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // Tile configuration
 // DBG (ablation builds of tools/kbench only): 1 = no global loads, 2 = no MFMA loop, 4 = no epilogue
 // DMA = 1: tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write);
 // two LDS buffers, the next tile's DMA is in flight while the current one is multiplied.
-template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0, int DMA_ = 0> struct Cfg {
+// BF = 1: bf16 matrix cores.  The LDS images stay f32; the 4 consecutive k a lane reads per q step are rounded
+// to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) and go through ONE v_mfma_f32_16x16x16_bf16 /
+// v_mfma_f32_32x32x8_bf16 (same lane -> (row, k) map as the four f32 MFMAs they replace), f32 accumulate.
+template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0, int DMA_ = 0, int BF_ = 0> struct Cfg {
     static constexpr int MF = MF_, BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_, PF = PF_;
-    static constexpr int DBG = DBG_, DMA = DMA_;
+    static constexpr int DBG = DBG_, DMA = DMA_, BF = BF_;
 };
+template <class C> struct WithBF { typedef Cfg<C::MF, C::BM, C::BN, C::BK, C::WM, C::WN, C::WK, C::PF, C::DBG, C::DMA, 1> type; };
 
 // Epilogue concept:
 //   plain         : void operator()(int z, int m, int n, float v) const
@@ -397,6 +423,18 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
 #pragma unroll
         for (int qq = 0; qq < QPW; ++qq) {
             if (qq + 1 < QPW) read_frags(As, Bs, wk * QPW + qq + 1, a[(qq + 1) & 1], b[(qq + 1) & 1]);
+            if constexpr (C::BF != 0) {
+                s16x4 ap[NTM], bp[NTN];
+#pragma unroll
+                for (int ta = 0; ta < NTM; ++ta) ap[ta] = pack_bf16(a[qq & 1][ta]);
+#pragma unroll
+                for (int tb = 0; tb < NTN; ++tb) bp[tb] = pack_bf16(b[qq & 1][tb]);
+#pragma unroll
+                for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NTN; ++tb) acc[ta][tb] = mfma_bf16<MF>(ap[ta], bp[tb], acc[ta][tb]);
+                continue;
+            }
 #pragma unroll
             for (int w = 0; w < 4; ++w)
 #pragma unroll

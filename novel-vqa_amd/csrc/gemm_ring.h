@@ -26,6 +26,7 @@
 // interface as gemm_f32.h.  LDS images and the k order are those of gemm_f32.h (16-byte chunks
 // XOR-swizzled by the row; the swizzle is applied to the DMA's per-lane SOURCE address).
 #pragma once
+#include <type_traits>
 #include "gemm_f32.h"
 
 namespace nvqa {
@@ -40,11 +41,12 @@ template <int OFF> __device__ __forceinline__ f32x4 lds_read_b128(uint32_t addr)
 #define NVQA_RING_S 4
 #define NVQA_RING_BK 32
 
-template <bool GATES, class Epi, int SEG>
+template <bool GATES, class Epi, int SEG, int S = NVQA_RING_S>
 __device__ __forceinline__ void gemm_ring_body(const GemmArgs &g, const Epi &epi, const int bx, const int by,
                                                const int bz)
 {
-    constexpr int BM = 64, BN = 64, BK = NVQA_RING_BK, S = NVQA_RING_S;
+    constexpr int BM = 64, BN = 64, BK = NVQA_RING_BK;
+    static_assert(S >= 2 && S <= 4, "ring stages");
     constexpr int STAGE = BM * BK + BN * BK; // floats per stage: A image then B image (16 KiB)
     constexpr int BU = BN / 4;               // GATES: units per block
     static_assert(SEG == 0 || SEG == 1, "SEG");
@@ -112,20 +114,20 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs &g, const Epi &epi
     }
     typedef __attribute__((address_space(3))) void *lds_t;
     typedef const __attribute__((address_space(1))) void *glb_t;
-    auto issue = [&](int kt) {
+    // operand = 0: A image, 1: B image; j = 0, 1: this wave's two pieces of it
+    auto issue_piece = [&](int kt, int operand, int j) {
         const bool s2 = SEG > 0 && kt >= nk1;
         const int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
-        float *st = smem + (kt % S) * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float *a = (SEG > 0 && s2 ? srcA[NSEG - 1][j] : srcA[0][j]) + k0;
-            __builtin_amdgcn_global_load_lds((glb_t)a, (lds_t)(st + (wave + 4 * j) * 256), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float *b = (SEG > 0 && s2 ? srcB[NSEG - 1][j] : srcB[0][j]) + k0;
-            __builtin_amdgcn_global_load_lds((glb_t)b, (lds_t)(st + BM * BK + (wave + 4 * j) * 256), 16, 0, 0);
-        }
+        float *st = smem + (kt % S) * STAGE + operand * (BM * BK) + (wave + 4 * j) * 256;
+        const float *src = operand == 0 ? (SEG > 0 && s2 ? srcA[NSEG - 1][j] : srcA[0][j])
+                                        : (SEG > 0 && s2 ? srcB[NSEG - 1][j] : srcB[0][j]);
+        __builtin_amdgcn_global_load_lds((glb_t)(src + k0), (lds_t)st, 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+        issue_piece(kt, 0, 0);
+        issue_piece(kt, 0, 1);
+        issue_piece(kt, 1, 0);
+        issue_piece(kt, 1, 1);
     };
 
     // fragment addresses (bytes): row * 128 + 16 * ((4 q + lh) ^ x), x = (row >> 1) & 7 = (li >> 1) & 7 for
@@ -138,41 +140,98 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs &g, const Epi &epi
     const uint32_t fb1 = BM * BK * 4 + li * (BK * 4) + 16 * ((4 + lh) ^ x);
     constexpr int TB = 16 * BK * 4; // bytes between the B rows of consecutive column tiles
 
-    auto mfma16 = [&](const f32x4 &a, const f32x4 (&b)[4]) {
+    // One K-tile of the pipelined loop: the 32 MFMAs of tile kt (fragments fc, already in registers) with,
+    // pinned between them by sched_barrier, the 10 fragment reads of tile kt+1 (into fn) and the 4 DMAs of
+    // tile kt+S (into the stage tile kt has just vacated).  A wave alone on its SIMD issues in order, so
+    // whatever is not placed inside the MFMA stream is exposed; placed there it costs (almost) nothing
+    // because an MFMA occupies the issue port for 8 of its 32 cycles.
+    struct Frag { f32x4 a[2], b[2][4]; };
+    auto tile = [&](auto next_c, auto issue_c, const Frag &fc, Frag &fn, int kt) {
+        constexpr bool NEXT = decltype(next_c)::value, ISSUE = decltype(issue_c)::value;
+        const uint32_t sb = sbase + (uint32_t)((kt + 1) % S) * (STAGE * 4);
+        int nm = 0; // MFMAs issued so far (compile-time after unrolling)
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-                acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[w], b[tb][w], acc[tb], 0, 0, 0);
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fc.a[q][w], fc.b[q][tb][w], acc[tb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++nm;
+                    if constexpr (NEXT) {
+                        if (nm == 1) fn.a[0] = lds_read_b128<0>(sb + fa0);
+                        if (nm == 2) fn.b[0][0] = lds_read_b128<0>(sb + fb0);
+                        if (nm == 3) fn.b[0][1] = lds_read_b128<TB>(sb + fb0);
+                        if (nm == 4) fn.b[0][2] = lds_read_b128<2 * TB>(sb + fb0);
+                        if (nm == 5) fn.b[0][3] = lds_read_b128<3 * TB>(sb + fb0);
+                        if (nm == 7) fn.a[1] = lds_read_b128<0>(sb + fa1);
+                        if (nm == 8) fn.b[1][0] = lds_read_b128<0>(sb + fb1);
+                        if (nm == 9) fn.b[1][1] = lds_read_b128<TB>(sb + fb1);
+                        if (nm == 10) fn.b[1][2] = lds_read_b128<2 * TB>(sb + fb1);
+                        if (nm == 11) fn.b[1][3] = lds_read_b128<3 * TB>(sb + fb1);
+                    }
+                    if constexpr (ISSUE) {
+                        if (nm == 13) issue_piece(kt + S, 0, 0);
+                        if (nm == 16) issue_piece(kt + S, 0, 1);
+                        if (nm == 19) issue_piece(kt + S, 1, 0);
+                        if (nm == 22) issue_piece(kt + S, 1, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        if constexpr (NEXT)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fn.a[0]), "+v"(fn.b[0][0]), "+v"(fn.b[0][1]), "+v"(fn.b[0][2]), "+v"(fn.b[0][3]), "+v"(fn.a[1]),
+                           "+v"(fn.b[1][0]), "+v"(fn.b[1][1]), "+v"(fn.b[1][2]), "+v"(fn.b[1][3]));
     };
 
     if (nk > 0) {
-        const int npre = min(S - 1, nk);
+        const int npre = min(S, nk);
         for (int kt = 0; kt < npre; ++kt) issue(kt);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int newer = min(nk - 1 - kt, S - 2); // tiles issued after kt that may stay in flight
-            if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + S - 1 < nk) issue(kt + S - 1);
-            const uint32_t sb = sbase + (uint32_t)(kt % S) * (STAGE * 4);
-            f32x4 a0, a1, b0[4], b1[4];
-            a0 = lds_read_b128<0>(sb + fa0);
-            b0[0] = lds_read_b128<0>(sb + fb0);
-            b0[1] = lds_read_b128<TB>(sb + fb0);
-            b0[2] = lds_read_b128<2 * TB>(sb + fb0);
-            b0[3] = lds_read_b128<3 * TB>(sb + fb0);
-            a1 = lds_read_b128<0>(sb + fa1);
-            b1[0] = lds_read_b128<0>(sb + fb1);
-            b1[1] = lds_read_b128<TB>(sb + fb1);
-            b1[2] = lds_read_b128<2 * TB>(sb + fb1);
-            b1[3] = lds_read_b128<3 * TB>(sb + fb1);
-            asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a0), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
-            mfma16(a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]));
-            mfma16(a1, b1);
+        // tile 0 has landed once at most npre - 1 newer tiles (4 DMAs each, in issue order) are in flight
+        if (npre >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (npre == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        Frag f[2];
+        {
+            const uint32_t sb = sbase;
+            f[0].a[0] = lds_read_b128<0>(sb + fa0);
+            f[0].b[0][0] = lds_read_b128<0>(sb + fb0);
+            f[0].b[0][1] = lds_read_b128<TB>(sb + fb0);
+            f[0].b[0][2] = lds_read_b128<2 * TB>(sb + fb0);
+            f[0].b[0][3] = lds_read_b128<3 * TB>(sb + fb0);
+            f[0].a[1] = lds_read_b128<0>(sb + fa1);
+            f[0].b[1][0] = lds_read_b128<0>(sb + fb1);
+            f[0].b[1][1] = lds_read_b128<TB>(sb + fb1);
+            f[0].b[1][2] = lds_read_b128<2 * TB>(sb + fb1);
+            f[0].b[1][3] = lds_read_b128<3 * TB>(sb + fb1);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0].a[0]), "+v"(f[0].b[0][0]), "+v"(f[0].b[0][1]), "+v"(f[0].b[0][2]), "+v"(f[0].b[0][3]),
+                           "+v"(f[0].a[1]), "+v"(f[0].b[1][0]), "+v"(f[0].b[1][1]), "+v"(f[0].b[1][2]), "+v"(f[0].b[1][3]));
+        }
+        auto step = [&](const Frag &fc, Frag &fn, int kt) {
+            if (kt + 1 < nk) {
+                // tile kt+1 must have landed: tiles up to min(nk, kt+S) - 1 are issued, those after kt+1 may stay in flight
+                const int newer = min(nk, kt + S) - (kt + 2);
+                if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // every wave's pieces of tile kt+1 are in LDS, and every wave has the fragments of tile kt in
+                // registers (its reads were waited for at the end of the previous step): stage kt % S is free
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + S < nk) tile(std::true_type{}, std::true_type{}, fc, fn, kt);
+                else tile(std::true_type{}, std::false_type{}, fc, fn, kt);
+            } else {
+                tile(std::false_type{}, std::false_type{}, fc, fn, kt);
+            }
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(f[0], f[1], kt);
+            if (kt + 1 < nk) step(f[1], f[0], kt + 1);
         }
     }
 
@@ -211,18 +270,18 @@ inline bool ring_ok(const GemmArgs &g, bool gates)
     return true;
 }
 
-template <bool GATES, class Epi, int SEG>
+template <bool GATES, class Epi, int SEG, int S>
 __global__ __launch_bounds__(256) void gemm_ring_multi_kernel(MultiArgs<Epi> a)
 {
     const int p = blockIdx.z / a.zsplit, z = blockIdx.z % a.zsplit;
-    gemm_ring_body<GATES, Epi, SEG>(a.g[p], a.e[p], blockIdx.x, blockIdx.y, z);
+    gemm_ring_body<GATES, Epi, SEG, S>(a.g[p], a.e[p], blockIdx.x, blockIdx.y, z);
 }
-template <bool GATES, class Epi, int SEG>
+template <bool GATES, class Epi, int SEG, int S = NVQA_RING_S>
 inline hipError_t launch_gemm_ring_multi(hipStream_t s, const MultiArgs<Epi> &a, int nprob)
 {
     const GemmArgs &g = a.g[0]; // all problems share M and N (grid shape)
     dim3 grid(GATES ? (g.N + 15) / 16 : (g.N + 63) / 64, (g.M + 63) / 64, nprob * a.zsplit);
-    hipLaunchKernelGGL((gemm_ring_multi_kernel<GATES, Epi, SEG>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_ring_multi_kernel<GATES, Epi, SEG, S>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

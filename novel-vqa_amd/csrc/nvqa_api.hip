@@ -100,13 +100,15 @@ typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/
 template <int AM, int BMo, class Epi>
 static int gemm_big(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
 {
-    NVQA_HIP((launch_gemm<CfgBig, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgBig>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    else NVQA_HIP((launch_gemm<CfgBig, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     return 0;
 }
 template <int AM, int BMo, class Epi>
 static int gemm_med(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
 {
-    NVQA_HIP((launch_gemm<CfgMed, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgMed>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    else NVQA_HIP((launch_gemm<CfgMed, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     return 0;
 }
 
@@ -240,9 +242,10 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
     NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * B * R));
-    {   // ring kernel: K-contiguous operands, K multiples of 32, whole 16-unit gate tiles
+    {   // LDS-DMA ring level kernels (gemm_ring.h): opt-in with NVQA_RING=1.  Measured equal to the
+        // register-staged kernels within +-4 % (tools/kbench6, kbench9), so they are not the default.
         const char *env = getenv("NVQA_RING");
-        c->use_ring = !(env && env[0] == '0') && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
+        c->use_ring = env && env[0] == '1' && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
         if (c->use_ring) NVQA_TRY(dalloc(&c->WT, (size_t)L * 2 * 4 * R * R));
     }
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
@@ -451,8 +454,10 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
         g.mseg_limits = c->nrows; g.seg_rows = B; // rows of not-yet-started questions are skipped
         // K-contiguous x K-contiguous: 64x64 tiles, 16x16x4 MFMA, 2 K-groups measured 119 TF vs 99 TF for
         // the 128x128 32x32x2 form (tools/kbench3)
-        NVQA_HIP((launch_gemm<Cfg<16, 64, 64, 32, 2, 2, 2, 1>, A_KC, B_KC, false, EpiBias2>(
-            c->s, g, EpiBias2{c->Gt[0], 4 * R, c->P + c->lo.b_i2h[0], c->P + c->lo.b_h2h[0]})));
+        typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgI2h;
+        const EpiBias2 e{c->Gt[0], 4 * R, c->P + c->lo.b_i2h[0], c->P + c->lo.b_h2h[0]};
+        if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgI2h>::type, A_KC, B_KC, false, EpiBias2>(c->s, g, e)));
+        else NVQA_HIP((launch_gemm<CfgI2h, A_KC, B_KC, false, EpiBias2>(c->s, g, e)));
     }
     // Wavefront over (layer, step): layer l at step t needs layer l at t-1 and layer l-1 at t, so
     // diagonal dg = t + l holds up to L independent steps; they go out as ONE launch.
@@ -489,9 +494,10 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
             ++np;
         }
         ProfScope ps(c, PF_LSTM_FWD, flops, bytes);
-        bool ring = c->use_ring;
+        bool ring = c->use_ring && !c->bf16;
         for (int i = 0; i < np && ring; ++i) ring = ring_ok(ma.g[i], true);
         if (ring) NVQA_HIP((launch_gemm_ring_multi<true, EpiLstmFwd, 1>(c->s, ma, np)));
+        else if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgLstmFwd>::type, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
         else NVQA_HIP((launch_gemm_multi<CfgLstmFwd, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
     }
     return 0;
@@ -506,7 +512,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
-    const bool ring = c->use_ring;
+    const bool ring = c->use_ring && !c->bf16;
     const size_t wt = (size_t)4 * R * R;
     if (ring) { // W_h2h^l [4R][R] -> [R][4R], W_i2h^l (l >= 1) likewise: the level products become K-contiguous x K-contiguous
         ProfScope ps(c, PF_TRANSPOSE, 0, (double)(2 * L - 1) * wt * 8);
@@ -573,6 +579,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z;
             if (ring) NVQA_HIP((launch_gemm_ring_multi<false, EpiStore, 0>(c->s, ma, np)));
+            else if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgBwdLevel>::type, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
             else NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
         {
@@ -648,7 +655,8 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             ma.g[1] = mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I, I / Zh);
             ma.e[1] = EpiStore{c->slabs + Zh * nBC, C, nBC};
             ma.zsplit = Zh;
-            NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMed>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            else NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
                                c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
         } else {
@@ -920,6 +928,14 @@ extern "C" int nvqa_set_fusion(nvqa_ctx *c, int askip)
     c->fusion_askip = askip;
     return 0;
 }
+extern "C" int nvqa_set_precision(nvqa_ctx *c, int bf16)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    if (bf16 != 0 && bf16 != 1) { set_error("precision must be 0 (f32) or 1 (bf16 operands)"); return -1; }
+    c->bf16 = bf16 != 0;
+    return 0;
+}
+
 extern "C" int nvqa_set_grad_scales(nvqa_ctx *c, const float scales[3])
 {
     if (!c || !scales) { set_error("NULL argument"); return -1; }

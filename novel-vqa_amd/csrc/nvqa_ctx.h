@@ -103,6 +103,7 @@ struct nvqa_ctx {
     float *colpart = nullptr, *slabs = nullptr;
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
     float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
+    bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate
     bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;

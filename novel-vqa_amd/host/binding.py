@@ -51,6 +51,7 @@ SYMBOLS = {
     "nvqa_forward": (ctypes.c_int, [_vp, ctypes.c_int32, _i32p, _i32p, _f32p, _f32p, _i32p]),
     "nvqa_rmsprop_update": (ctypes.c_int, [_vp] + [ctypes.c_float] * 5),
     "nvqa_set_fusion": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "nvqa_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_set_grad_scales": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_dataset_load": (ctypes.c_int, [_vp, ctypes.c_int64, _i32p, _i32p, _i32p, _i32p,
                                          ctypes.c_int64, _f32p, ctypes.c_int]),
@@ -214,6 +215,9 @@ class Context:
 
     def set_fusion(self, askip):
         self._check(self.lib.nvqa_set_fusion(self._h, int(askip)))
+
+    def set_precision(self, bf16):
+        self._check(self.lib.nvqa_set_precision(self._h, int(bool(bf16))))
 
     def set_grad_scales(self, scales):
         a = np.ascontiguousarray(scales, np.float32)

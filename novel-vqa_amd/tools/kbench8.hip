@@ -1,4 +1,4 @@
-// kbench7.hip -- the LSTM recurrence is independent per batch row: does splitting the batch into NCH
+// kbench8.hip -- operand-value sensitivity of the level kernel (derived from kbench7): does splitting the batch into NCH
 // independent chains of level kernels, one HIP stream each, let one chain's launch / prologue / epilogue
 // latency hide under another chain's MFMA phase?  Forward level (layer-0 step K = 512; layer-1 step
 // K = 512 + 512), B = 512 rows in all, register-staged and LDS-DMA ring kernels.
@@ -36,7 +36,7 @@ template <int RING> static float chains(int nch, int iters, hipStream_t *st)
     auto go = [&](int n) {
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < nch; ++c) {
-                if (RING) launch_gemm_ring_multi<true, EpiLstmFwd, 1, RING ? RING : 4>(st[c], ma[c], 2);
+                if (RING) launch_gemm_ring_multi<true, EpiLstmFwd, 1>(st[c], ma[c], 2);
                 else launch_gemm_multi<Prod, A_KC, B_KC, true, EpiLstmFwd, 1>(st[c], ma[c], 2);
             }
     };
@@ -55,19 +55,20 @@ int main()
 {
     hipMalloc(&dW, (size_t)2 * 4 * R * R * 4); hipMalloc(&dH, (size_t)4 * B * R * 4); hipMalloc(&dC, (size_t)2 * B * R * 4);
     hipMalloc(&dG, (size_t)2 * B * 4 * R * 4); hipMalloc(&dU, (size_t)B * R * 4); hipMalloc(&dN, 4); hipMalloc(&dSI, B * 4);
-    std::vector<float> h((size_t)2 * 4 * R * R);
-    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 5000.f - 0.1f;
-    hipMemcpy(dW, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dH, h.data(), (size_t)4 * B * R * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dC, h.data(), (size_t)2 * B * R * 4, hipMemcpyHostToDevice); hipMemcpy(dG, h.data(), (size_t)2 * B * 4 * R * 4, hipMemcpyHostToDevice);
     int n = B; hipMemcpy(dN, &n, 4, hipMemcpyHostToDevice); std::vector<int> si(B); for (int i = 0; i < B; ++i) si[i] = i;
     hipMemcpy(dSI, si.data(), B * 4, hipMemcpyHostToDevice);
-    hipStream_t st[8];
-    int lo, hi; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    for (int c = 0; c < 8; ++c) hipStreamCreateWithPriority(&st[c], hipStreamNonBlocking, hi);
-    printf("forward level (3.2 GFLOP per 512 rows, floor 20.5 us): us per level of the whole batch\n");
-    for (int nch : {1, 2, 4}) {
-        printf("  %d chain(s) of %3d rows: register-staged %7.2f us   ring S=2 (32 KB) %7.2f   S=3 (48 KB) %7.2f   S=4 (64 KB) %7.2f us\n", nch, B / nch,
-               chains<0>(nch, 200, st), chains<2>(nch, 200, st), chains<3>(nch, 200, st), chains<4>(nch, 200, st));
+    hipStream_t st[1]; hipStreamCreate(&st[0]);
+    std::vector<float> h((size_t)2 * 4 * R * R);
+    printf("is the level kernel slowed by its operand VALUES (power / clock) rather than by its loads?  us per level\n");
+    for (int mode = 0; mode < 4; ++mode) {
+        for (size_t i = 0; i < h.size(); ++i) {
+            const float rnd = (float)((i * 2654435761u) % 1000) / 5000.f - 0.1f;
+            h[i] = mode == 0 ? rnd : mode == 1 ? 0.f : mode == 2 ? 1.0f : (float)((i * 2654435761u) >> 9) * (1.0f / 8388608.f) - 0.5f;
+        }
+        hipMemcpy(dW, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dH, h.data(), (size_t)4 * B * R * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dC, h.data(), (size_t)2 * B * R * 4, hipMemcpyHostToDevice); hipMemcpy(dG, h.data(), (size_t)2 * B * 4 * R * 4, hipMemcpyHostToDevice);
+        const char *nm[] = {"3-digit pseudo-random (kbench data)", "all zero", "all 1.0", "full-mantissa pseudo-random"};
+        printf("  %-38s register-staged %7.2f us   LDS-DMA ring %7.2f us\n", nm[mode], chains<0>(1, 300, st), chains<1>(1, 300, st));
     }
     return 0;
 }

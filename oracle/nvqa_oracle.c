@@ -54,8 +54,36 @@ static real drop_scale(const nvqa_dropout *dr, uint32_t site, uint64_t idx)
 }
 
 /* y[n x out] = x[n x in] W^T + b            (nn.Linear forward) */
+/* bf16 operand mode (BASELINE config "arch2 ... bf16", nvqa_set_precision): every operand of a dense
+ * product is rounded to bf16 (round-to-nearest-even, as v_cvt_pk_bf16_f32 does) before it is multiplied;
+ * sums, biases, bias gradients and everything else stay in `real`. */
+static int g_bf16 = 0;
+void oracle_set_precision(int bf16) { g_bf16 = bf16; }
+static real bf16_round(real v)
+{
+    float f = (float)v;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return v; /* NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return (real)f;
+}
+/* rounded copy of an operand (NULL when the mode is off: the caller then uses the original) */
+static real *bf16_copy(const real *p, size_t n)
+{
+    if (!g_bf16) return NULL;
+    real *q = (real *)malloc((n ? n : 1) * sizeof(real));
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) q[i] = bf16_round(p[i]);
+    return q;
+}
+
 static void lin_fwd(int n, int out, int in, const real *x, const real *W, const real *b, real *y)
 {
+    real *xb = bf16_copy(x, (size_t)n * in), *Wb = bf16_copy(W, (size_t)out * in);
+    if (xb) { x = xb; W = Wb; }
 #pragma omp parallel for collapse(2) schedule(static)
     for (int r = 0; r < n; ++r)
         for (int o = 0; o < out; ++o) {
@@ -65,11 +93,15 @@ static void lin_fwd(int n, int out, int in, const real *x, const real *W, const 
             for (int k = 0; k < in; ++k) acc += xr[k] * w[k];
             y[(size_t)r * out + o] = acc + (b ? b[o] : (real)0);
         }
+    free(xb);
+    free(Wb);
 }
 
 /* dx[n x in] (+)= dy[n x out] W            (nn.Linear updateGradInput) */
 static void lin_bwd_dx(int n, int out, int in, const real *dy, const real *W, real *dx, int accumulate)
 {
+    real *gb = bf16_copy(dy, (size_t)n * out), *Wb = bf16_copy(W, (size_t)out * in);
+    if (gb) { dy = gb; W = Wb; }
 #pragma omp parallel for schedule(static)
     for (int r = 0; r < n; ++r) {
         real *d = dx + (size_t)r * in;
@@ -81,24 +113,31 @@ static void lin_bwd_dx(int n, int out, int in, const real *dy, const real *W, re
             for (int k = 0; k < in; ++k) d[k] += g * w[k];
         }
     }
+    free(gb);
+    free(Wb);
 }
 
 /* dW[out x in] += dy^T x ; db[out] += colsum(dy)   (nn.Linear accGradParameters) */
 static void lin_bwd_dw(int n, int out, int in, const real *dy, const real *x, real *dW, real *db)
 {
+    real *gb = bf16_copy(dy, (size_t)n * out), *xb = bf16_copy(x, (size_t)n * in);
+    const real *dyq = gb ? gb : dy; /* the bias gradient is a plain column sum of the unrounded dy */
+    if (xb) x = xb;
 #pragma omp parallel for schedule(static)
     for (int o = 0; o < out; ++o) {
         real *w = dW + (size_t)o * in;
         real bs = 0;
         for (int r = 0; r < n; ++r) {
-            const real g = dy[(size_t)r * out + o];
+            const real g = dyq[(size_t)r * out + o];
             const real *xr = x + (size_t)r * in;
-            bs += g;
+            bs += dy[(size_t)r * out + o];
 #pragma omp simd
             for (int k = 0; k < in; ++k) w[k] += g * xr[k];
         }
         if (db) db[o] += bs;
     }
+    free(gb);
+    free(xb);
 }
 
 static real sigm(real x) { return (real)1 / ((real)1 + (real)exp(-(double)x)); }

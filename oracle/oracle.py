@@ -144,6 +144,10 @@ class Oracle:
         """0 = netdef.AxB, 1 = netdef.AskipB (process-wide switch of the oracle library)."""
         self.lib.oracle_set_fusion(int(askip))
 
+    def set_precision(self, bf16):
+        """1 = every operand of a dense product rounded to bf16 first (nvqa_set_precision); process-wide."""
+        self.lib.oracle_set_precision(int(bool(bf16)))
+
     def rmsprop(self, x, g, m, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
         """In place on x, g (clamped, + wd x), m."""
         for a in (x, g, m):

@@ -16,6 +16,34 @@ import torch
 M64 = (1 << 64) - 1
 
 
+# bf16 operand mode (nvqa_set_precision / oracle.set_precision): both operands of every dense product are
+# rounded to bf16 (torch's f32 -> bf16 cast rounds to nearest even) in the forward AND in the two backward
+# products; biases and bias gradients are untouched.  Stated as a custom autograd function so that it
+# is independent of the oracle's loop nests.
+BF16 = False
+
+
+def _r(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _BfMatmul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return _r(x) @ _r(W).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        return _r(dy) @ _r(W), _r(dy).t() @ _r(x)
+
+
+def lin(x, W, b):
+    """nn.Linear: y = x W^T + b."""
+    return (_BfMatmul.apply(x, W) if BF16 else x @ W.t()) + b
+
+
 def hash32(seed, step, site, idx):
     """Python restatement of nvqa_hash32 (include/nvqa_rng.h)."""
     x = (seed ^ ((0x9E3779B97F4A7C15 * (step + 1)) & M64) ^ ((site << 56) & M64)) & M64
@@ -76,8 +104,8 @@ def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True
         for l in range(L):
             inn = E if l == 0 else R
             u = x if l == 0 else Dl[l][:, t, :] * h[l - 1]
-            a = u @ p[f"w_i2h{l}"].view(4 * R, inn).t() + p[f"b_i2h{l}"] \
-                + h[l] @ p[f"w_h2h{l}"].view(4 * R, R).t() + p[f"b_h2h{l}"]
+            a = lin(u, p[f"w_i2h{l}"].view(4 * R, inn), p[f"b_i2h{l}"]) \
+                + lin(h[l], p[f"w_h2h{l}"].view(4 * R, R), p[f"b_h2h{l}"])
             cn, hn = _cell(a, c[l], R)
             # rows that have not started keep their zero state (RNNUtils.lua:136-145)
             c[l] = active * cn
@@ -88,10 +116,10 @@ def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True
     Dv = drop_scales(drr, 3, (B, I), lambda b, j: b * I + j)
     Dz = drop_scales(drr, 4, (B, C), lambda b, j: b * C + j)
     v = torch.tensor(np.asarray(img, np.float64).reshape(B, I))
-    qc = torch.tanh((Dq * q) @ p["w_q"].view(C, Q).t() + p["b_q"])
-    ic = torch.tanh((Dv * v) @ p["w_v"].view(C, I).t() + p["b_v"])
+    qc = torch.tanh(lin(Dq * q, p["w_q"].view(C, Q), p["b_q"]))
+    ic = torch.tanh(lin(Dv * v, p["w_v"].view(C, I), p["b_v"]))
     fused = qc + qc * ic if askip else qc * ic  # netdef.AskipB / netdef.AxB
-    scores = (Dz * fused) @ p["w_o"].view(A, C).t() + p["b_o"]
+    scores = lin(Dz * fused, p["w_o"].view(A, C), p["b_o"])
     y = torch.tensor(np.asarray(labels, np.int64) - 1)
     loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
     grads = None
@@ -117,7 +145,7 @@ def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True):
                    for l in range(1, L)]
     for t in range(1, TS + 1):
         if t == 1:
-            x = v @ p["w_p"].view(E, I).t() + p["b_p"]
+            x = lin(v, p["w_p"].view(E, I), p["b_p"])
         elif t == 2:
             x = Wlk[V].expand(B, E)
         else:
@@ -129,11 +157,11 @@ def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True):
         for l in range(L):
             inn = E if l == 0 else R
             u = x if l == 0 else Dl[l][:, t - 1, :] * h[l - 1]
-            a = u @ p[f"w_i2h{l}"].view(4 * R, inn).t() + p[f"b_i2h{l}"] \
-                + h[l] @ p[f"w_h2h{l}"].view(4 * R, R).t() + p[f"b_h2h{l}"]
+            a = lin(u, p[f"w_i2h{l}"].view(4 * R, inn), p[f"b_i2h{l}"]) \
+                + lin(h[l], p[f"w_h2h{l}"].view(4 * R, R), p[f"b_h2h{l}"])
             c[l], h[l] = _cell(a, c[l], R)
     Dh = drop_scales(drr, 2, (B, R), lambda b, j: b * R + j)
-    scores = (Dh * h[L - 1]) @ p["w_o"].view(A, R).t() + p["b_o"]
+    scores = lin(Dh * h[L - 1], p["w_o"].view(A, R), p["b_o"])
     y = torch.tensor(np.asarray(labels, np.int64) - 1)
     loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
     grads = None

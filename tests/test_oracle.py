@@ -180,3 +180,32 @@ def test_golden_vectors(orc, name):
         assert abs(tr["grads"][o_:o_ + n_].astype(np.float64).sum() - s) < 1e-4 * a + 1e-9, k
     if "grads" in g:
         assert relmax(tr["grads"], g["grads"]) < 1e-5
+
+
+@pytest.mark.parametrize("arch", [1, 2])
+def test_bf16_operand_mode_matches_independent_autograd(orc, arch):
+    """BASELINE config "arch2 ... bf16" (nvqa_set_precision): operands of every dense product rounded to
+    bf16, sums in the working precision.  The f64 oracle keeps activations in f64, the autograd model too, so
+    both round the same values: agreement stays at the 1e-12 level; against the f32-mode result the loss moves
+    by about the bf16 epsilon."""
+    d, params, (tok, lens, img, lab) = _setup(orc, arch)
+    dr = orc.Dropout(1, 0.5, 123, 7)
+    lo = orc.layout(d)
+    o = orc.Oracle(np.float64)
+    exact = o.step(d, params, tok, lens, img, lab, dr)
+    o.set_precision(1)
+    ra.BF16 = True
+    try:
+        ref = (ra.arch1(d, lo, params, tok, lens, img, lab, dr) if arch == 1
+               else ra.arch2(d, lo, params, tok, img, lab, dr))
+        got = o.step(d, params, tok, lens, img, lab, dr)
+    finally:
+        o.set_precision(0)
+        ra.BF16 = False
+    assert abs(got["loss"] - ref["loss"]) < 1e-12
+    assert relmax(got["scores"], ref["scores"]) < 1e-12
+    assert relmax(got["grads"], ref["grads"]) < 1e-12
+    dl = abs(got["loss"] - exact["loss"]) / abs(exact["loss"])
+    assert 1e-7 < dl < 2e-2, dl          # the mode is on, and it is a bf16-sized perturbation
+    again = o.step(d, params, tok, lens, img, lab, dr)
+    assert again["loss"] == exact["loss"]  # switched off again
