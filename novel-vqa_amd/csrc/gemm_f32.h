@@ -72,7 +72,21 @@ struct GemmArgs {
     // A_MC / B_NC product are grouped -> all-zero K-tiles are skipped.
     const int *mseg_limits, *kseg_limits;
     int seg_rows;
+    // XCD-aware tile order (single-problem launches): workgroups are dealt round-robin over the 8 XCDs, so
+    // with the natural order the tiles that share an operand block (same row block, neighbouring column
+    // tiles; same K slice) land on 8 different L2s and the block is fetched from HBM up to 8 times.  With
+    // xcd = 1 the hardware id is folded so that each XCD owns one contiguous range of the x-fastest tile order.
+    int xcd;
 };
+
+// hardware workgroup id (x fastest) -> logical tile id, a bijection on [0, total): XCD k = id % 8 receives the
+// contiguous logical range [k * per, ...) in dispatch order; the first total % 8 XCDs hold one tile more.
+__device__ __forceinline__ unsigned xcd_fold(unsigned id, unsigned total)
+{
+    const unsigned per = (total + 7) / 8, tall = total % 8 ? total % 8 : 8;
+    const unsigned x = id % 8, local = id / 8;
+    return x < tall ? x * per + local : tall * per + (x - tall) * (per - 1) + local;
+}
 
 template <int MF> struct AccT;
 template <> struct AccT<32> { typedef f32x16 type; };
@@ -643,7 +657,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG = 0>
 __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_kernel(GemmArgs g, Epi epi)
 {
-    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(g, epi, blockIdx.x, blockIdx.y, blockIdx.z);
+    if (g.xcd) {
+        const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+        const unsigned j = xcd_fold(blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), total);
+        gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(g, epi, j % nx, (j / nx) % ny, j / (nx * ny));
+    } else {
+        gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(g, epi, blockIdx.x, blockIdx.y, blockIdx.z);
+    }
 }
 
 // Several independent problems of the same shape class in ONE launch (blockIdx.z = problem):

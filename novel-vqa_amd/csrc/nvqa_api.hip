@@ -112,10 +112,18 @@ static int gemm_med(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st
     return 0;
 }
 
+// NVQA_XCD=0 keeps the natural tile order (for A/B measurements of the XCD-aware order)
+static int xcd_order()
+{
+    static const int v = [] { const char *e = getenv("NVQA_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 static GemmArgs mkargs(const float *A, int lda, const float *B, int ldb, int M, int N, int K,
                        int kslice = 0, int R = 0, const int *mlimit = nullptr)
 {
     GemmArgs g = {};
+    g.xcd = xcd_order();
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
     g.kslice = kslice > 0 ? kslice : (K > 0 ? K : 1);
     g.R = R; g.mlimit = mlimit;

@@ -10,6 +10,7 @@
 // K = 9*C_in), bias+ReLU fused in the epilogue; fc6/fc7 are split-K GEMMs (M = batch is small, the
 // 411 MB fc6 weight stream is the cost) with bias+ReLU fused into the slab reduction.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -241,6 +242,12 @@ extern "C" int nvqa_vgg16_set_weights(nvqa_vgg *v, const float *flat)
     return 0;
 }
 
+static int xcd_order() // NVQA_XCD=0: natural tile order (A/B measurements)
+{
+    static const int v = [] { const char *e = getenv("NVQA_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, const float *b, float *out)
 {
     const int N = v->F;
@@ -250,6 +257,7 @@ static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, c
     ks = (K + kslice - 1) / kslice;
     GemmArgs g = {};
     g.A = x; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kslice = kslice;
+    g.xcd = xcd_order();
     NVQA_HIP((launch_gemm<CfgFc, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
     hipLaunchKernelGGL(k_fc_finish, dim3(((size_t)M * N + 255) / 256), dim3(256), 0, v->s, v->slabs, ks, M, N, b, out);
     NVQA_HIP(hipGetLastError());
@@ -275,6 +283,7 @@ static int vgg_forward(nvqa_vgg *v, const float *images, int n)
         g.A = cur; g.B = v->Wc[i]; g.ldb = 9 * v->cinp[i];
         g.M = n * H * W; g.N = v->cout[i]; g.K = 9 * v->cinp[i]; g.kslice = g.K;
         g.cH = H; g.cW = W; g.cC = v->cinp[i];
+        g.xcd = xcd_order(); // neighbouring pixel-row tiles (shared halo rows) and all C_out tiles of a row tile on one XCD
         // output channel stride = padded C_out, so that the next layer reads float4 channels; the pad
         // channels must be zero: they are written by nobody, so clear once when padding exists
         const int ldc = v->coutp[i];
