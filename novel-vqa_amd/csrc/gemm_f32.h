@@ -674,12 +674,20 @@ template <class Epi> struct MultiArgs {
     GemmArgs g[NVQA_MULTI_MAX];
     Epi e[NVQA_MULTI_MAX];
     int zsplit = 1; // K slices per problem (cross-CU split-K: the epilogue sees z and writes a slab)
+    int xcd = 0;    // fold the hardware workgroup id so that each XCD owns a contiguous range of the x-fastest
+                    // (tile, K slice, problem) order: one K slice of one problem per XCD shares its operand slabs in L2
 };
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
 __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_multi_kernel(MultiArgs<Epi> a)
 {
-    const int p = blockIdx.z / a.zsplit, z = blockIdx.z % a.zsplit;
-    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(a.g[p], a.e[p], blockIdx.x, blockIdx.y, z);
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {
+        const unsigned nx = gridDim.x, ny = gridDim.y;
+        const unsigned j = xcd_fold(bx + nx * (by + ny * bz), nx * ny * gridDim.z);
+        bx = j % nx; by = (j / nx) % ny; bz = j / (nx * ny);
+    }
+    const int p = bz / a.zsplit, z = bz % a.zsplit;
+    gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(a.g[p], a.e[p], bx, by, z);
 }
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
 inline hipError_t launch_gemm_multi(hipStream_t s, const MultiArgs<Epi> &a, int nprob)

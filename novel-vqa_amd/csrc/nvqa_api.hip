@@ -194,7 +194,7 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
         NVQA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         NVQA_HIP(hipStreamCreateWithPriority(&c->s, hipStreamNonBlocking, greatest));
         NVQA_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, greatest));
-        for (int i = 0; i < 3; ++i) NVQA_HIP(hipEventCreateWithFlags(&c->evSeg[i], hipEventDisableTiming));
+        for (int i = 0; i < 3 + NVQA_MAX_LAYERS; ++i) NVQA_HIP(hipEventCreateWithFlags(&c->evSeg[i], hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evComm, hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
     }
@@ -283,7 +283,9 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
         if (c->U[l]) (void)hipFree(c->U[l]);
     }
     if (c->h_loss) (void)hipHostFree(c->h_loss);
-    for (hipEvent_t e : {c->evSeg[0], c->evSeg[1], c->evSeg[2], c->evComm, c->evStart})
+    for (hipEvent_t e : {c->evComm, c->evStart})
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->evSeg)
         if (e) (void)hipEventDestroy(e);
     if (c->sc) (void)hipStreamDestroy(c->sc);
     if (c->s) (void)hipStreamDestroy(c->s);
@@ -516,7 +518,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 // and (dX0 != NULL) dX0 holds dL/d(layer-0 input).  Same wavefront as the forward pass, top
 // layer first; the time-batched weight-gradient GEMMs of a layer start on the low-priority
 // bulk stream as soon as that layer's last step is done.
-static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
+static int lstm_backward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
@@ -586,6 +588,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
         if (np > 0) {
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z;
+            ma.xcd = xcd_order(); // natural order: every XCD reads all of dG (105 MB of fabric traffic per level, PMC)
             if (ring) NVQA_HIP((launch_gemm_ring_multi<false, EpiStore, 0>(c->s, ma, np)));
             else if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgBwdLevel>::type, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
             else NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
@@ -596,17 +599,26 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr, float *dX0)
         }
         NVQA_HIP(hipGetLastError());
     }
-    // Time-batched products, after the chains, one after the other on the main stream: each of them
-    // fills the chip by itself (split-K), so extra streams bought nothing (measured), and overlapping
-    // them with the latency-critical chain kernels only slowed the chain (5.2 vs 4.5 ms per step).
-    // Weight gradients are sums over all steps (002_train_baseline.lua:323-326).
-    for (int l = L - 1; l >= 0; --l) {
-        const int in = l == 0 ? d.E : R;
-        const float *Xin = l == 0 ? c->X0 : c->U[l];
-        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s));
-        NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s));
-        NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
-    }
+    return 0;
+}
+
+// Weight gradients of layer l, sums over all steps (002_train_baseline.lua:323-326): two time-batched
+// split-K products and the bias column sums.  They run after the chains, one after the other on the main
+// stream: each fills the chip by itself (split-K), so extra streams bought nothing (measured), and
+// overlapping them with the latency-critical chain kernels only slowed the chain (5.2 vs 4.5 ms per step).
+// In data parallel the layer's slice of the flat gradient goes out right behind them (reduce_range), so
+// only the last, smallest slice is not hidden under compute.
+static int reduce_range(nvqa_ctx *c, size_t off, size_t count, int ev);
+static int lstm_wgrads(nvqa_ctx *c, int l)
+{
+    const nvqa_dims &d = c->d;
+    const int R = d.R, TB = c->TS * d.B;
+    const int in = l == 0 ? d.E : R;
+    const float *Xin = l == 0 ? c->X0 : c->U[l];
+    NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s));
+    NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s));
+    NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
+    NVQA_TRY(reduce_range(c, c->lo.w_i2h[l], c->lo.b_h2h[l] + 4 * (size_t)R - c->lo.w_i2h[l], 3 + l));
     return 0;
 }
 
@@ -713,8 +725,9 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(colsum(c, c->dic, B, C, C, G + c->lo.b_v, nullptr));
     NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
     float *dX0 = c->dX0;
-    NVQA_TRY(lstm_backward(c, dr, dX0));
-    NVQA_TRY(reduce_segment(c, 0)); // encoder: overlaps d(input), the embedding gradient and its column sum
+    NVQA_TRY(lstm_backward(c, dr));
+    // embedding gradient first, so that its 11.8 MB all-reduce and those of the upper LSTM layers travel
+    // under the weight-gradient GEMMs; only layer 0's slice (5.8 MB) is exchanged after the last kernel
     NVQA_TRY(lstm_dx0(c, dX0));
     {
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
@@ -726,6 +739,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_HIP(hipGetLastError());
     NVQA_TRY(colsum(c, G + c->lo.w_e, V, E, E, G + c->lo.b_e, nullptr));
     NVQA_TRY(reduce_segment(c, 1)); // embedding
+    for (int l = L - 1; l >= 0; --l) NVQA_TRY(lstm_wgrads(c, l)); // + the layer's slice of the encoder segment
     return 0;
 }
 
@@ -787,13 +801,14 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     }
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
     NVQA_TRY(reduce_segment(c, 2)); // classifier
-    NVQA_TRY(lstm_backward(c, dr, c->dX0));
+    NVQA_TRY(lstm_backward(c, dr));
     NVQA_TRY(lstm_dx0(c, c->dX0));
     {   // cnn_projection:backward (002_train_baseline.lua:322): dW_p = dx_1^T fv_im, db_p = colsum(dx_1)
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 2.0 * B * E * I, ((double)B * (E + I) + (double)E * I) * 4);
         NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dX0, E, c->img, I, E, I, B), EpiStore{G + c->lo.w_p, I, 0})));
     }
     NVQA_TRY(colsum(c, c->dX0, B, E, E, G + c->lo.b_p, nullptr));
+    NVQA_TRY(reduce_segment(c, 0)); // cnn projection
     {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)(V + 1) * E) * 4);
         const int waves = 4;
@@ -802,8 +817,8 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
                            c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
     }
     NVQA_HIP(hipGetLastError());
-    NVQA_TRY(reduce_segment(c, 0)); // cnn projection
-    NVQA_TRY(reduce_segment(c, 1)); // encoder (LSTM + lookup table)
+    NVQA_TRY(reduce_range(c, c->lo.w_lk, (size_t)(V + 1) * E, 1)); // lookup table: travels under the weight-gradient GEMMs
+    for (int l = L - 1; l >= 0; --l) NVQA_TRY(lstm_wgrads(c, l));  // + each layer's slice of the encoder segment
     return 0;
 }
 
@@ -1126,17 +1141,21 @@ extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
 // encoder, embedding), so the largest bucket travels over xGMI while BPTT is still running.
 // The 1/world scale and the clamp stay in k_rmsprop: the clamp must act on the mean
 // (002_train_baseline.lua:329 is non-linear).  Every rank issues the same calls in the same order.
-static int reduce_segment(nvqa_ctx *c, int seg)
+static int reduce_range(nvqa_ctx *c, size_t off, size_t count, int ev)
 {
-    if (!c->comm) return 0;
-    size_t off = 0;
-    for (int i = 0; i < seg; ++i) off += c->lo.seg[i];
-    NVQA_HIP(hipEventRecord(c->evSeg[seg], c->s));
-    NVQA_HIP(hipStreamWaitEvent(c->sc, c->evSeg[seg], 0));
-    ProfScope ps(c, PF_ALLREDUCE, 0, 4.0 * c->lo.seg[seg], c->sc);
-    const int rc = g_rccl.AllReduce(c->G + off, c->G + off, c->lo.seg[seg], /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
+    if (!c->comm || count == 0) return 0;
+    NVQA_HIP(hipEventRecord(c->evSeg[ev], c->s));
+    NVQA_HIP(hipStreamWaitEvent(c->sc, c->evSeg[ev], 0));
+    ProfScope ps(c, PF_ALLREDUCE, 0, 4.0 * count, c->sc);
+    const int rc = g_rccl.AllReduce(c->G + off, c->G + off, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
     if (rc) { set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
     return 0;
+}
+static int reduce_segment(nvqa_ctx *c, int seg)
+{
+    size_t off = 0;
+    for (int i = 0; i < seg; ++i) off += c->lo.seg[i];
+    return reduce_range(c, off, c->lo.seg[seg], seg);
 }
 static void comm_destroy(nvqa_ctx *c)
 {

@@ -73,7 +73,7 @@ struct nvqa_ctx {
     hipStream_t s = nullptr;                     // compute stream
     hipEvent_t evStart = nullptr;                // hand-off from the extractor's stream (nvqa_step_images)
     hipStream_t sc = nullptr;                    // communication stream (RCCL all-reduce buckets)
-    hipEvent_t evSeg[3] = {}, evComm = nullptr;  // segment ready / exchange done
+    hipEvent_t evSeg[3 + NVQA_MAX_LAYERS] = {}, evComm = nullptr; // gradient range ready (3 segments + per-layer slices) / exchange done
     int TS = 0; // recurrent steps: arch1 T, arch2 T+2
 
     // parameters / gradients / RMSprop mean-square (internal layout = ABI layout with the
