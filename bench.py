@@ -27,6 +27,9 @@ import __graft_entry__ as ge  # noqa: E402
 
 # BASELINE.json configs[1]: arch1 baseline, VGG fc7 feats, 1000-way answers, batch 512 fp32
 WORKLOAD = dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000)
+# BASELINE.json configs[3] (secondary, --arch 2): arch2 "deeper LSTM + Inception-v3 feats": -num_layers 2,
+# -nhimage 2048 (001_prepro_img_inc.lua:82), E = R = 512, T + 2 = 28 encoder steps, weight decay 1e-4
+WORKLOAD_ARCH2 = dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=2, I=2048, C=4, A=1000)
 N_QUESTIONS, N_IMAGES = 65536, 8192
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
@@ -37,6 +40,10 @@ def flops_per_qa(w):
     3 x forward (fwd + dgrad + wgrad) minus the never-computed gradient to the image input;
     the embedding is a gather (0 FLOP)."""
     E, R, L, I, C, A, T = w["E"], w["R"], w["L"], w["I"], w["C"], w["A"], w["T"]
+    if w["arch"] == 2:  # image projection + (T+2) encoder steps + classifier; the lookup is a gather
+        per_tok = sum(2 * 4 * R * ((E if l == 0 else R) + R) for l in range(L))
+        fwd = (T + 2) * per_tok + 2 * E * I + 2 * A * R
+        return 3 * fwd - 2 * E * I, fwd
     per_tok = 0
     for l in range(L):
         inn = E if l == 0 else R
@@ -53,7 +60,10 @@ def synth_dataset(w, seed, ragged=False):
     lens = np.full(N_QUESTIONS, w["T"], np.int32)
     if ragged:  # secondary case: lengths ~ U{3..T}, right-aligned, 0 = left padding
         lens = rng.integers(3, w["T"] + 1, N_QUESTIONS).astype(np.int32)
-        q[np.arange(w["T"])[None, :] < (w["T"] - lens)[:, None]] = 0
+        if w["arch"] == 1:
+            q[np.arange(w["T"])[None, :] < (w["T"] - lens)[:, None]] = 0
+        else:           # arch2 keeps the stored left-aligned rows, 0 = null after the question
+            q[np.arange(w["T"])[None, :] >= lens[:, None]] = 0
     img_pos = rng.integers(1, N_IMAGES + 1, N_QUESTIONS, dtype=np.int32)
     ans = rng.integers(1, w["A"] + 1, N_QUESTIONS, dtype=np.int32)
     feats = np.abs(rng.standard_normal((N_IMAGES, w["I"]), dtype=np.float32))  # normalised on device
@@ -87,6 +97,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="secondary case: question lengths ~ U{3..26}")
+    ap.add_argument("--arch", type=int, default=1, choices=(1, 2),
+                    help="2 = secondary case: arch2 deeper LSTM + Inception feats (BASELINE configs[3])")
     ap.add_argument("--bf16", action="store_true",
                     help="secondary case: nvqa_set_precision(1), dense products on the bf16 matrix cores "
                          "(operands rounded to bf16, f32 accumulate); the headline metric is the f32 run")
@@ -108,7 +120,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = ge.load_package()
-    w = WORKLOAD
+    w = WORKLOAD if args.arch == 1 else WORKLOAD_ARCH2
     dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
     tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123)
     tr.init_params()  # same on every rank (counter-based)
@@ -149,11 +161,12 @@ def main():
     peak = BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS
     value = w["B"] * world * args.steps / dt
     out = {
-        "metric": "QA-pairs/sec training step (batch 512, seq 26)", "value": round(value, 1),
+        "metric": "QA-pairs/sec training step (batch 512, seq 26)" + ("" if args.arch == 1 else " [arch2, secondary]"), "value": round(value, 1),
         "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 operands, f32 accumulate" if args.bf16 else "f32", "data": "synthetic",
-        "config": {"workload": "arch1 002_train_baseline: V=14773 E=200 R=512 L=2 I=4096 C=1024 A=1000, "
+        "config": {"workload": ("arch1 002_train_baseline: V=14773 E=200 R=512 L=2 I=4096 C=1024 A=1000, " if args.arch == 1 else
+                                "arch2 002_train_baseline (deeper LSTM + Inception feats): V=14773 E=R=512 L=2 I=2048 A=1000, 28 steps, wd 1e-4, ")
                                + ("lengths U{3..26}" if args.ragged else "all lengths 26") + ", dropout 0.5 on, HBM-resident dataset, RMSprop",
                    "global_batch": w["B"] * world, "seq_len": w["T"], "parallelism": f"dp{world}"},
         "flop_per_qa": fl_qa,

@@ -302,48 +302,75 @@ __global__ void k_reduce_slabs(const float *slabs, int S, size_t n4, float4 *C)
 // [E x sum(len)] x [sum(len) x V] GEMM over the one-hot matrix.
 // ---------------------------------------------------------------------------------
 #define NVQA_EB_ROWS 16
+#define NVQA_EB_COLS 128 // columns per workgroup: LDS = waves x 16 x 128 floats = 32 KB whatever E is
 __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, const int32_t *sort_idx,
                           int NP /*T*B*/, int B, int T, int V, int E, Drop dr, float *dWeT /*[V][E]*/,
                           int plain /* 1: nn.LookupTable (arch2): the row gradient is dX itself */)
 {
-    // A workgroup owns 16 vocabulary rows; its waves scan consecutive quarters of the packed token
-    // list into private LDS accumulators, which are then summed in wave order: a fixed summation
-    // order (ascending packed position within a wave, waves in order), so still bit-reproducible.
-    extern __shared__ float acc[]; // [waves][16][E]
+    // A workgroup owns 16 vocabulary rows x 128 columns (blockIdx.y = column block; with E = 512 one block per
+    // row range needed 128 KB of LDS, one workgroup per CU, and the 512 START-token rows of arch2 went through
+    // one wave 8 columns-of-64 at a time: 1.49 ms).  Its waves scan consecutive quarters of the packed token
+    // list into private LDS accumulators, which are then summed in wave order: a fixed summation order
+    // (ascending packed position within a wave, waves in order), so still bit-reproducible.
+    extern __shared__ float acc[]; // [waves][16][EC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
     const int v0 = blockIdx.x * NVQA_EB_ROWS;
-    float *my = acc + (size_t)wave * NVQA_EB_ROWS * E;
-    for (int i = lane; i < NVQA_EB_ROWS * E; i += 64) my[i] = 0.f;
+    const int e0 = blockIdx.y * NVQA_EB_COLS, EC = min(NVQA_EB_COLS, E - e0);
+    float *my = acc + (size_t)wave * NVQA_EB_ROWS * NVQA_EB_COLS;
+    for (int i = lane; i < NVQA_EB_ROWS * NVQA_EB_COLS; i += 64) my[i] = 0.f;
     const int per = ((NP + waves - 1) / waves + 63) / 64 * 64;
     const int kbeg = wave * per, kend = min(NP, kbeg + per);
+    const bool c0 = lane < EC, c1 = lane + 64 < EC; // this lane's two columns of the block
+    auto fetch = [&](int kk, float &a0, float &a1) {
+        const size_t g = (size_t)kk * E + e0 + lane;
+        a0 = c0 ? dX[g] : 0.f;
+        a1 = c1 ? dX[g + 64] : 0.f;
+        if (!plain) {
+            const int t = kk / B, r = kk % B;
+            const uint64_t base = ((uint64_t)sort_idx[r] * T + t) * E + e0 + lane;
+            if (c0) { const float x = X[g]; a0 = dr.scale(NVQA_SITE_EMB, base) * (a0 * (1.0f - x * x)); }
+            if (c1) { const float x = X[g + 64]; a1 = dr.scale(NVQA_SITE_EMB, base + 64) * (a1 * (1.0f - x * x)); }
+        }
+    };
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
         const int k = k0 + lane;
         const int w = k < kend ? ptok[k] : -1;
         unsigned long long hit = __ballot(w >= v0 && w < v0 + NVQA_EB_ROWS);
+        if (!hit) continue;
+        // hits in ascending packed order, eight at a time: their rows are requested together (a frequent word's
+        // chain of hits is latency-bound otherwise) and added in order
         while (hit) {
-            const int src = __ffsll((long long)hit) - 1;
-            hit &= hit - 1;
-            const int kk = k0 + src;
-            const int row = __shfl(w, src, 64) - v0;
-            const int t = kk / B, r = kk % B;
-            const uint64_t base = ((uint64_t)sort_idx[r] * T + t) * E;
-            for (int e = lane; e < E; e += 64) {
-                float dp = dX[(size_t)kk * E + e];
-                if (!plain) {
-                    const float x = X[(size_t)kk * E + e];
-                    dp = dr.scale(NVQA_SITE_EMB, base + e) * (dp * (1.0f - x * x));
+            int src[8];
+            float a0[8], a1[8];
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                src[i] = -1;
+                if (hit) {
+                    src[i] = __ffsll((long long)hit) - 1;
+                    hit &= hit - 1;
+                    fetch(k0 + src[i], a0[i], a1[i]);
+                    ++n;
                 }
-                my[row * E + e] += dp;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i >= n) break;
+                const int row = __shfl(w, src[i], 64) - v0;
+                my[row * NVQA_EB_COLS + lane] += a0[i];
+                my[row * NVQA_EB_COLS + lane + 64] += a1[i];
             }
         }
     }
     __syncthreads();
     const int nr = min(NVQA_EB_ROWS, V - v0);
-    for (int i = threadIdx.x; i < nr * E; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nr * NVQA_EB_COLS; i += blockDim.x) {
+        const int row = i / NVQA_EB_COLS, col = i % NVQA_EB_COLS;
+        if (col >= EC) continue;
         float s = 0.f;
-        for (int wv = 0; wv < waves; ++wv) s += acc[(size_t)wv * NVQA_EB_ROWS * E + i];
-        dWeT[(size_t)v0 * E + i] = s;
+        for (int wv = 0; wv < waves; ++wv) s += acc[(size_t)wv * NVQA_EB_ROWS * NVQA_EB_COLS + i];
+        dWeT[(size_t)(v0 + row) * E + e0 + col] = s;
     }
 }
 

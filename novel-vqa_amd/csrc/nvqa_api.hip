@@ -731,9 +731,10 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(lstm_dx0(c, dX0));
     {
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
-        const int waves = 4;
+        const int waves = 8;
         const int blocks = (V + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
-        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
+        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks, (E + NVQA_EB_COLS - 1) / NVQA_EB_COLS), dim3(64 * waves),
+                           (size_t)waves * NVQA_EB_ROWS * NVQA_EB_COLS * sizeof(float), c->s,
                            c->ptok, c->X0, dX0, c->sort_idx, TB, B, T, V, E, dr, G + c->lo.w_e, 0);
     }
     NVQA_HIP(hipGetLastError());
@@ -811,9 +812,10 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(reduce_segment(c, 0)); // cnn projection
     {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)(V + 1) * E) * 4);
-        const int waves = 4;
+        const int waves = 8;
         const int blocks = (V + 1 + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
-        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks), dim3(64 * waves), (size_t)waves * NVQA_EB_ROWS * E * sizeof(float), c->s,
+        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks, (E + NVQA_EB_COLS - 1) / NVQA_EB_COLS), dim3(64 * waves),
+                           (size_t)waves * NVQA_EB_ROWS * NVQA_EB_COLS * sizeof(float), c->s,
                            c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
     }
     NVQA_HIP(hipGetLastError());
