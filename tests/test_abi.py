@@ -51,3 +51,15 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower().replace("cpu oracle", "").replace("the oracle", ""), \
                     f"{f} references the oracle"
+
+
+def test_lua_cdef_declares_every_header_function():
+    """novel-vqa_amd/lua/nvqa_ffi.lua is the reference-side binding: its ffi.cdef must name
+    every function include/nvqa.h declares, or a LuaJIT caller cannot reach it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "nvqa.h")).read()
+    lua = open(os.path.join(root, "novel-vqa_amd", "lua", "nvqa_ffi.lua")).read()
+    names = set(re.findall(r"\b(nvqa_[a-z0-9_]+)\s*\(", hdr))
+    missing = sorted(n for n in names if not re.search(r"\b%s\s*\(" % n, lua))
+    assert not missing, missing
