@@ -114,3 +114,72 @@ def test_arch1_step_and_update_against_torch_nn_modules(orc, mode):
         assert relmax(xo, x.detach().numpy()) < 1e-12
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_arch2_step_against_torch_nn_modules(orc):
+    """arch2 (003_train_vqa_arch2: image-as-first-token encoder, shared nn.LookupTable, START token = row V+1,
+    nulls rewritten to word 1, Encoder_lstm.lua:152-227) from torch.nn.Embedding / LSTMCell / Linear."""
+    d = orc.make_dims(arch=2, B=5, T=6, V=11, E=8, R=8, L=2, I=12, C=4, A=8)
+    B, T, V, E, R, L, I, A = d.B, d.T, d.V, d.E, d.R, d.L, d.I, d.A
+    TS = T + 2
+    params = orc.synth_params(d).astype(np.float64)
+    tok, _, img, lab = orc.synth_batch(d, full_length=False)
+    dr = orc.Dropout(1, 0.5, 123, 3)
+    lo = orc.layout(d)
+    p = {k: torch.tensor(params[v[0]:v[0] + v[1]]) for k, v in lo.items() if not k.startswith("_")}
+    torch.set_default_dtype(torch.float64)
+    try:
+        lookup = torch.nn.Embedding(V + 1, E)
+        lookup.weight.data = p["w_lk"].view(V + 1, E).clone()
+        proj, cls = torch.nn.Linear(I, E), torch.nn.Linear(R, A)
+        proj.weight.data, proj.bias.data = p["w_p"].view(E, I).clone(), p["b_p"].clone()
+        cls.weight.data, cls.bias.data = p["w_o"].view(A, R).clone(), p["b_o"].clone()
+        cells = []
+        for l in range(L):
+            inn = E if l == 0 else R
+            cell = torch.nn.LSTMCell(inn, R)
+            cell.weight_ih.data = _perm_ifog_to_ifgo(p[f"w_i2h{l}"].view(4 * R, inn), R)
+            cell.weight_hh.data = _perm_ifog_to_ifgo(p[f"w_h2h{l}"].view(4 * R, R), R)
+            cell.bias_ih.data = _perm_ifog_to_ifgo(p[f"b_i2h{l}"], R)
+            cell.bias_hh.data = _perm_ifog_to_ifgo(p[f"b_h2h{l}"], R)
+            cells.append(cell)
+        Dl = [None] + [ra.drop_scales(dr, 1, (B, TS, R), lambda b, t, j, l=l: (((l - 1) * B + b) * TS + t) * R + j)
+                       for l in range(1, L)]
+        Dh = ra.drop_scales(dr, 2, (B, R), lambda b, j: b * R + j)
+        toks = np.asarray(tok).reshape(B, T)
+        h = [torch.zeros(B, R) for _ in range(L)]
+        c = [torch.zeros(B, R) for _ in range(L)]
+        for t in range(1, TS + 1):
+            if t == 1:
+                x = proj(torch.tensor(np.asarray(img, np.float64)))
+            elif t == 2:
+                x = lookup(torch.full((B,), V, dtype=torch.int64))
+            else:
+                it = toks[:, t - 3].copy()
+                if it.sum() == 0:
+                    break
+                it[it == 0] = 1
+                x = lookup(torch.tensor(it.astype(np.int64) - 1))
+            for l in range(L):
+                u = x if l == 0 else Dl[l][:, t - 1, :] * h[l - 1]
+                h[l], c[l] = cells[l](u, (h[l], c[l]))
+        scores = cls(Dh * h[L - 1])
+        loss = torch.nn.CrossEntropyLoss()(scores, torch.tensor(np.asarray(lab, np.int64) - 1))
+        loss.backward()
+        got = orc.Oracle(np.float64).step(d, params, tok, None, img, lab, dr)
+        assert abs(got["loss"] - float(loss.detach())) < 1e-12
+
+        def back(g):
+            return torch.cat([g[0:R], g[R:2 * R], g[3 * R:4 * R], g[2 * R:3 * R]], 0)
+
+        want = {"w_lk": lookup.weight.grad.reshape(-1), "w_p": proj.weight.grad.reshape(-1), "b_p": proj.bias.grad,
+                "w_o": cls.weight.grad.reshape(-1), "b_o": cls.bias.grad}
+        for l in range(L):
+            want[f"w_i2h{l}"] = back(cells[l].weight_ih.grad).reshape(-1)
+            want[f"w_h2h{l}"] = back(cells[l].weight_hh.grad).reshape(-1)
+            want[f"b_i2h{l}"] = back(cells[l].bias_ih.grad)
+            want[f"b_h2h{l}"] = back(cells[l].bias_hh.grad)
+        for k, (o, n) in ((k, v) for k, v in lo.items() if not k.startswith("_")):
+            assert relmax(got["grads"][o:o + n], want[k].numpy()) < 1e-10, k
+    finally:
+        torch.set_default_dtype(torch.float32)
