@@ -8,8 +8,11 @@
  * PARITY UNPINNED: the reference (Lua/Torch7) cannot run in the build
  * environment and ships no tests, fixtures or golden vectors, so this file is
  * a restatement of the equations read from the cited lines; it is
- * cross-checked against an independent autograd model (tests/ref_autograd.py)
- * and finite differences, not against Torch7 output.
+ * cross-checked against an independent autograd model (tests/ref_autograd.py),
+ * against PyTorch's own nn / optim modules -- LSTMCell, Linear, Embedding,
+ * CrossEntropyLoss, optim.RMSprop, the descendants of the Torch7 packages the
+ * reference calls (tests/test_oracle_torch_modules.py, agreement to 1e-10) --
+ * and against finite differences, not against Torch7 output.
  *
  * Follows (paths relative to the reference checkout):
  *   arch1 step     002_train_vqa_arch1/002_train_baseline.lua:272-335
