@@ -94,12 +94,14 @@ __global__ void k_l2norm_copy(const float *src, int n, int I, float *dst)
 __global__ void k_sort_lengths(const int32_t *len, int B, int T, int32_t *sort_idx, int32_t *sort_inv,
                                int32_t *nrows /*[T]*/)
 {
-    extern __shared__ int sm[]; // hist[T+1], start[T+1]
-    int *hist = sm, *start = sm + (T + 1);
+    extern __shared__ int sm[]; // hist[T+1], start[T+1], sl[B] (the clamped lengths: the stable rank below reads
+                                // every earlier row's length, from LDS (broadcast reads) instead of from global memory)
+    int *hist = sm, *start = sm + (T + 1), *sl = sm + 2 * (T + 1);
     for (int i = threadIdx.x; i <= T; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const int l = min(max(len[b], 0), T);
+        sl[b] = l;
         atomicAdd(&hist[l], 1);
     }
     __syncthreads();
@@ -109,9 +111,9 @@ __global__ void k_sort_lengths(const int32_t *len, int B, int T, int32_t *sort_i
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const int l = min(max(len[b], 0), T);
+        const int l = sl[b];
         int rank = 0;
-        for (int c = 0; c < b; ++c) rank += (min(max(len[c], 0), T) == l);
+        for (int c = 0; c < b; ++c) rank += (sl[c] == l);
         const int pos = start[l] + rank;
         sort_idx[pos] = b;
         sort_inv[b] = pos;

@@ -645,7 +645,7 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     const int TB = T * B;
     {
         ProfScope ps(c, PF_ASSEMBLE);
-        hipLaunchKernelGGL(k_sort_lengths, dim3(1), dim3(1024), (2 * (T + 1)) * sizeof(int), c->s, c->len, B, T,
+        hipLaunchKernelGGL(k_sort_lengths, dim3(1), dim3(1024), (2 * (T + 1) + B) * sizeof(int), c->s, c->len, B, T,
                            c->sort_idx, c->sort_inv, c->nrows);
     }
     {
