@@ -720,9 +720,22 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dqc, C, c->P + c->lo.w_q, Q, B, Q, C),
                                        EpiResort{c->dCT, c->dHT, c->sort_inv, B, R, Q, dr})));
     }
-    NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
-    NVQA_TRY(colsum(c, c->dqc, B, C, C, G + c->lo.b_q, nullptr));
-    NVQA_TRY(colsum(c, c->dic, B, C, C, G + c->lo.b_v, nullptr));
+    {   // b_o, b_q, b_v: three B-row column sums in one launch
+        ProfScope ps(c, PF_COLSUM, 0, (double)B * (A + 2.0 * C) * 4);
+        ColsumBatch cb = {};
+        const float *Xs[3] = {c->dscores, c->dqc, c->dic};
+        float *outs[3] = {G + c->lo.b_o, G + c->lo.b_q, G + c->lo.b_v};
+        const int Ns[3] = {A, C, C};
+        int blocks = 0;
+        for (int i = 0; i < 3; ++i) {
+            cb.X[i] = Xs[i]; cb.out[i] = outs[i]; cb.M[i] = B; cb.N[i] = Ns[i]; cb.ld[i] = Ns[i];
+            cb.first_block[i] = blocks;
+            blocks += (Ns[i] + 63) / 64;
+        }
+        cb.first_block[3] = cb.first_block[4] = blocks;
+        hipLaunchKernelGGL(k_colsum_batch, dim3(blocks), dim3(256), 0, c->s, cb);
+        NVQA_HIP(hipGetLastError());
+    }
     NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
     float *dX0 = c->dX0;
     NVQA_TRY(lstm_backward(c, dr));
