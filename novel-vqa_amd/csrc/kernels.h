@@ -174,13 +174,23 @@ __global__ void k_head_prep(const float *Cfin /*[L][B][R]*/, const float *Hfin, 
 {
     const int b = blockIdx.x, r = sort_inv[b];
     const int Q = 2 * R * L;
-    for (int j = threadIdx.x; j < Q; j += blockDim.x) {
+    // 16-byte accesses (R % 4 == 0, I % 4 == 0 are preconditions of nvqa_create): 4 consecutive j stay inside
+    // one (layer, c | h) run of R values
+    for (int j = 4 * threadIdx.x; j < Q; j += 4 * blockDim.x) {
         const int l = j / (2 * R), part = (j / R) & 1, u = j % R;
-        const float *src = (part ? Hfin : Cfin) + (size_t)l * lstride + (size_t)r * R + u;
-        qd[(size_t)b * Q + j] = dr.scale(NVQA_SITE_Q, (uint64_t)b * Q + j) * (*src);
+        const float4 v = *reinterpret_cast<const float4 *>((part ? Hfin : Cfin) + (size_t)l * lstride + (size_t)r * R + u);
+        const uint64_t idx = (uint64_t)b * Q + j;
+        *reinterpret_cast<float4 *>(qd + idx) =
+            make_float4(dr.scale(NVQA_SITE_Q, idx) * v.x, dr.scale(NVQA_SITE_Q, idx + 1) * v.y,
+                        dr.scale(NVQA_SITE_Q, idx + 2) * v.z, dr.scale(NVQA_SITE_Q, idx + 3) * v.w);
     }
-    for (int j = threadIdx.x; j < I; j += blockDim.x)
-        vd[(size_t)b * I + j] = dr.scale(NVQA_SITE_V, (uint64_t)b * I + j) * img[(size_t)b * I + j];
+    for (int j = 4 * threadIdx.x; j < I; j += 4 * blockDim.x) {
+        const uint64_t idx = (uint64_t)b * I + j;
+        const float4 v = *reinterpret_cast<const float4 *>(img + idx);
+        *reinterpret_cast<float4 *>(vd + idx) =
+            make_float4(dr.scale(NVQA_SITE_V, idx) * v.x, dr.scale(NVQA_SITE_V, idx + 1) * v.y,
+                        dr.scale(NVQA_SITE_V, idx + 2) * v.z, dr.scale(NVQA_SITE_V, idx + 3) * v.w);
+    }
 }
 
 // ---------------------------------------------------------------------------------
