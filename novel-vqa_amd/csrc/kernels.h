@@ -378,9 +378,19 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
             if (c1) { const float x = X[g + 64]; a1 = dr.scale(NVQA_SITE_EMB, base + 64) * (a1 * (1.0f - x * x)); }
         }
     };
-    for (int k0 = kbeg; k0 < kend; k0 += 64) {
-        const int k = k0 + lane;
-        const int w = k < kend ? ptok[k] : -1;
+    // the token list is read eight 64-token chunks at a time (independent loads in flight: a wave's scan is
+    // a chain of L2 round trips otherwise and almost every chunk has no hit for these 16 rows)
+    for (int kb = kbeg; kb < kend; kb += 8 * 64) {
+      int wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+          const int k = kb + 64 * j + lane;
+          wv[j] = k < kend ? ptok[k] : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k0 = kb + 64 * j;
+        const int w = wv[j];
         unsigned long long hit = __ballot(w >= v0 && w < v0 + NVQA_EB_ROWS);
         if (!hit) continue;
         // hits in ascending packed order, eight at a time: their rows are requested together (a frequent word's
@@ -407,6 +417,7 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
                 my[row * NVQA_EB_COLS + lane + 64] += a1[i];
             }
         }
+      }
     }
     __syncthreads();
     const int nr = min(NVQA_EB_ROWS, V - v0);
