@@ -332,6 +332,25 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         if (!inb) sB[j] = -1;
     }
 
+    // A_IM2COL: output pixel (n, y, x) of each staged row, decomposed ONCE (rows do not change over the K
+    // loop); imP = address of that pixel's channel 0 in the NHWC input, NULL for rows beyond the image batch
+    const float *imP[AMODE == A_IM2COL ? NA : 1];
+    int imY[AMODE == A_IM2COL ? NA : 1], imX[AMODE == A_IM2COL ? NA : 1];
+    if constexpr (AMODE == A_IM2COL) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int f = tid + j * NT;
+            const int m = m0 + f / (BK / 4);
+            imP[j] = nullptr; imY[j] = 0; imX[j] = 0;
+            if ((A_F4 % NT == 0 || f < A_F4) && m < mlim) {
+                const int hw = g.cH * g.cW;
+                const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
+                imY[j] = y; imX[j] = x;
+                imP[j] = g.A + (((size_t)n * g.cH + y) * g.cW + x) * g.cC;
+            }
+        }
+    }
+
     auto load_tiles = [&](int kt, float4(&ra)[NA], float4(&rb)[NB]) {
         if constexpr (C::DBG & 1) {
 #pragma unroll
@@ -353,20 +372,21 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
             kit_next += BK;
         }
         const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
+        int tap0 = 0, cK0 = 0;
+        if constexpr (AMODE == A_IM2COL) { tap0 = k0 / g.cC; cK0 = k0 - tap0 * g.cC; }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (AMODE == A_IM2COL) {
-                const int f = tid + j * NT;
-                const int row = f / (BK / 4), m = m0 + row, k = k0 + kA[j];
-                if ((A_F4 % NT == 0 || f < A_F4) && m < mlim && k < kend) {
-                    const int hw = g.cH * g.cW;
-                    const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
-                    const int tap = k / g.cC, ci = k - tap * g.cC, ky = tap / 3, kx = tap - ky * 3;
-                    const int iy = y + ky - 1, ix = x + kx - 1;
-                    if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
-                        v = *reinterpret_cast<const float4 *>(g.A + (((size_t)n * g.cH + iy) * g.cW + ix) * g.cC + ci);
-                }
+                // k -> (tap, channel): k0 is uniform, so the division by the channel count is done once per tile;
+                // a staged float4 crosses into the next tap(s) only when a tap is narrower than the tile (C_in < BK)
+                int ci = cK0 + kA[j], tap = tap0;
+                if (g.cC < BK) { tap += ci / g.cC; ci %= g.cC; }
+                else if (ci >= g.cC) { ci -= g.cC; ++tap; }
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int iy = imY[j] + ky - 1, ix = imX[j] + kx - 1;
+                if (imP[j] && k0 + kA[j] < kend && iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
+                    v = *reinterpret_cast<const float4 *>(imP[j] + ((ptrdiff_t)(ky - 1) * g.cW + (kx - 1)) * g.cC + ci);
             } else {
                 const float *p = SEG > 0 && s2 ? pA[NSEG - 1][j] : pA[0][j];
                 if (p && k0 + kA[j] < kend)
