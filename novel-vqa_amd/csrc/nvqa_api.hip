@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "gemm_f32.h"
@@ -93,6 +94,7 @@ static void prof_collect(nvqa_ctx *c)
 //                 MF   BM   BN   BK  WM WN WK PF
 typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgMed;
+typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgMedKK; // K-contiguous x K-contiguous M = B products: 16x16x4, 2 K-groups (tools/kbench3: 117.6 vs 104.5 TF)
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
 typedef Cfg<16, 64, 64, 64, 4, 1, 2, 1> CfgLstmFwd; // 8 waves: 2 K-groups x 4 row tiles of 16 rows x 16 units x 4 gates (tools/kbench4: 37.5 vs 44.3 us per level)
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/kbench2: 34.2 vs 38.9 us per level for the 32x32x2 form)
@@ -107,8 +109,9 @@ static int gemm_big(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st
 template <int AM, int BMo, class Epi>
 static int gemm_med(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
 {
-    if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgMed>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
-    else NVQA_HIP((launch_gemm<CfgMed, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    typedef typename std::conditional<AM == A_KC && BMo == B_KC, CfgMedKK, CfgMed>::type C;
+    if (c->bf16) NVQA_HIP((launch_gemm<typename WithBF<C>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    else NVQA_HIP((launch_gemm<C, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     return 0;
 }
 
@@ -675,8 +678,8 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             ma.g[1] = mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I, I / Zh);
             ma.e[1] = EpiStore{c->slabs + Zh * nBC, C, nBC};
             ma.zsplit = Zh;
-            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMed>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
-            else NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMedKK>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            else NVQA_HIP((launch_gemm_multi<CfgMedKK, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
                                c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
         } else {

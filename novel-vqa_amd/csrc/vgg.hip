@@ -112,7 +112,7 @@ __global__ void k_vgg_preprocess(const float *in, int n, int H, int W, int S, fl
 
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgConv;   // C_out >= 128: 8 waves of 32 x 64, 16x16x4 MFMA (tools/kbench3: 117 vs 95 TF for the K-contiguous x K-contiguous form)
 typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1> CfgConv64;  // C_out <= 64
-typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgFc;
+typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgFc;
 
 } // namespace
 
