@@ -93,25 +93,28 @@ static void prof_collect(nvqa_ctx *c)
 // BPTT level      : 64x64x32 split-K products into slabs + k_lstm_bwd_finish
 //                 MF   BM   BN   BK  WM WN WK PF
 typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
-typedef Cfg<32, 64, 64, 32, 2, 2, 1, 2> CfgMed;
-typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgMedKK; // K-contiguous x K-contiguous M = B products: 16x16x4, 2 K-groups (tools/kbench3: 117.6 vs 104.5 TF)
+// tools/kbench10 (sweep over the head / d(input) / i2h shapes): 8 waves of 16 x 32 (64x64) or 32 x 64 (128x128) with
+// the 16x16x4 MFMA beat the 4-wave 32x32x2 forms by 5-10 % in every layout except the long-K weight gradients
+typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgMed;
+typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgBig16;
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
 typedef Cfg<16, 64, 64, 64, 4, 1, 2, 1> CfgLstmFwd; // 8 waves: 2 K-groups x 4 row tiles of 16 rows x 16 units x 4 gates (tools/kbench4: 37.5 vs 44.3 us per level)
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/kbench2: 34.2 vs 38.9 us per level for the 32x32x2 form)
 
-template <int AM, int BMo, class Epi>
+// LONGK: the time-batched weight gradients (K = T*B): the 4-wave 32x32x2 form is the faster one there
+template <int AM, int BMo, class Epi, bool LONGK = false>
 static int gemm_big(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
 {
-    if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgBig>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
-    else NVQA_HIP((launch_gemm<CfgBig, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    typedef typename std::conditional<LONGK, CfgBig, CfgBig16>::type C;
+    if (c->bf16) NVQA_HIP((launch_gemm<typename WithBF<C>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    else NVQA_HIP((launch_gemm<C, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     return 0;
 }
 template <int AM, int BMo, class Epi>
 static int gemm_med(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
 {
-    typedef typename std::conditional<AM == A_KC && BMo == B_KC, CfgMedKK, CfgMed>::type C;
-    if (c->bf16) NVQA_HIP((launch_gemm<typename WithBF<C>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
-    else NVQA_HIP((launch_gemm<C, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgMed>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+    else NVQA_HIP((launch_gemm<CfgMed, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     return 0;
 }
 
@@ -439,10 +442,10 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
         GemmArgs g = mkargs(A, lda, Bm, ldb, M, N, K, kslice);
         g.kseg_limits = c->nrows; g.seg_rows = c->d.B; // K rows = (step, sorted row): skip the zero padding
         if (ks == 1) {
-            NVQA_TRY((gemm_big<A_MC, B_NC>(c, g, EpiStore{dW, N, 0}, st)));
+            NVQA_TRY((gemm_big<A_MC, B_NC, EpiStore, true>(c, g, EpiStore{dW, N, 0}, st)));
             return 0;
         }
-        NVQA_TRY((gemm_big<A_MC, B_NC>(c, g, EpiStore{slabs, N, (size_t)M * N}, st)));
+        NVQA_TRY((gemm_big<A_MC, B_NC, EpiStore, true>(c, g, EpiStore{slabs, N, (size_t)M * N}, st)));
     }
     ProfScope ps(c, PF_REDUCE, 0, (double)(ks + 1) * M * N * 4, st);
     const size_t n4 = (size_t)M * N / 4;
@@ -467,7 +470,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
         g.mseg_limits = c->nrows; g.seg_rows = B; // rows of not-yet-started questions are skipped
         // K-contiguous x K-contiguous: 64x64 tiles, 16x16x4 MFMA, 2 K-groups measured 119 TF vs 99 TF for
         // the 128x128 32x32x2 form (tools/kbench3)
-        typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgI2h;
+        typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgI2h;
         const EpiBias2 e{c->Gt[0], 4 * R, c->P + c->lo.b_i2h[0], c->P + c->lo.b_h2h[0]};
         if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgI2h>::type, A_KC, B_KC, false, EpiBias2>(c->s, g, e)));
         else NVQA_HIP((launch_gemm<CfgI2h, A_KC, B_KC, false, EpiBias2>(c->s, g, e)));
@@ -678,8 +681,8 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             ma.g[1] = mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I, I / Zh);
             ma.e[1] = EpiStore{c->slabs + Zh * nBC, C, nBC};
             ma.zsplit = Zh;
-            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMedKK>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
-            else NVQA_HIP((launch_gemm_multi<CfgMedKK, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMed>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            else NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
                                c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
         } else {
