@@ -13,7 +13,7 @@ import glob
 import json
 import sys
 
-from pmc_traffic import GROUPS
+from pmc_traffic import GROUPS, match
 
 CLOCK_HZ, SIMDS = 2.38e9, 1024
 
@@ -23,7 +23,7 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         for g, pred in GROUPS:
-            if pred(r["Kernel_Name"]):
+            if match(pred, r):
                 a = agg[g]
                 a[r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":

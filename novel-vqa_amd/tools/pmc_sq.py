@@ -13,7 +13,7 @@ import glob
 import json
 import sys
 
-from pmc_traffic import GROUPS
+from pmc_traffic import GROUPS, match
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     n = collections.defaultdict(collections.Counter)
     for r in csv.DictReader(open(f)):
         for g, pred in GROUPS:
-            if pred(r["Kernel_Name"]):
+            if match(pred, r):
                 agg[g][r["Counter_Name"]] += float(r["Counter_Value"])
                 n[g][r["Counter_Name"]] += 1
                 break

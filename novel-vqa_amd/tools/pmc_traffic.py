@@ -19,13 +19,22 @@ GROUPS = [
     ("lstm_step_bwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiStore" in n),
     ("lstm_bwd_finish", lambda n: "k_lstm_bwd_finish" in n),
     ("gemm_wgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n),
-    ("gemm_i2h_fwd", lambda n: "gemm_f32_kernel" in n and "EpiBias2" in n and "Cfg<16, 64, 64, 32, 2, 2, 2, 1" in n),
+    # i2h forward and the classifier's W_o product share a kernel (EpiBias2, K-contiguous x K-contiguous): the
+    # time-batched one is the launch with more than a million threads
+    ("gemm_i2h_fwd", lambda n, grid=0: "gemm_f32_kernel" in n and "EpiBias2" in n and grid > (1 << 20)),
     ("gemm_dgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 0, 1, false" in n and "EpiStore" in n),
     ("rmsprop", lambda n: "k_rmsprop" in n),
     ("emb_bwd", lambda n: "k_emb_bwd" in n),
     ("emb_fwd", lambda n: "k_emb_fwd" in n),
     ("softmax_ce", lambda n: "k_softmax_ce" in n),
 ]
+
+
+def match(pred, row):
+    """predicates take the kernel name, and optionally the launch's thread count as `grid`"""
+    if pred.__code__.co_argcount > 1:
+        return pred(row["Kernel_Name"], int(row.get("Grid_Size", 0) or 0))
+    return pred(row["Kernel_Name"])
 
 
 def collect(d, counter):
@@ -35,7 +44,7 @@ def collect(d, counter):
         if r["Counter_Name"] != counter:
             continue
         for g, pred in GROUPS:
-            if pred(r["Kernel_Name"]):
+            if match(pred, r):
                 agg[g] += float(r["Counter_Value"])
                 cnt[g] += 1
                 break
