@@ -97,6 +97,8 @@ typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 // the 16x16x4 MFMA beat the 4-wave 32x32x2 forms by 5-10 % in every layout except the long-K weight gradients
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgMed;
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgBig16;
+typedef Cfg<16, 64, 32, 32, 4, 2, 1, 1> CfgNarrow; // 64 x 32 tiles, 8 waves of 16 x 16: products whose 64 x 64 tiling leaves half the
+                                                   // CUs idle (W_o, dzd: 128 tiles; 20 vs 27 us) or whose N wastes wide tiles (d(input), N = 200: 122 vs 140 us)
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
 typedef Cfg<16, 64, 64, 64, 4, 1, 2, 1> CfgLstmFwd; // 8 waves: 2 K-groups x 4 row tiles of 16 rows x 16 units x 4 gates (tools/kbench4: 37.5 vs 44.3 us per level)
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/kbench2: 34.2 vs 38.9 us per level for the 32x32x2 form)
@@ -113,6 +115,11 @@ static int gemm_big(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st
 template <int AM, int BMo, class Epi>
 static int gemm_med(nvqa_ctx *c, const GemmArgs &g, const Epi &e, hipStream_t st = nullptr)
 {
+    if (((g.M + 63) / 64) * ((g.N + 63) / 64) <= 160) { // fewer tiles than CUs: halve the tile
+        if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgNarrow>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+        else NVQA_HIP((launch_gemm<CfgNarrow, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
+        return 0;
+    }
     if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgMed>::type, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     else NVQA_HIP((launch_gemm<CfgMed, AM, BMo, false, Epi>(st ? st : c->s, g, e)));
     return 0;
@@ -637,6 +644,13 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
     ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
     GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
     g.mseg_limits = c->nrows; g.seg_rows = d.B;
+    // N = E: 128-wide tiles waste (256 - 200) / 256 of the MFMA work at the reference's E = 200, 32-wide ones 24 / 224
+    const int w128 = (d.E + 127) / 128 * 128, w32 = (d.E + 31) / 32 * 32;
+    if (w32 * 10 <= w128 * 9) {
+        if (c->bf16) NVQA_HIP((launch_gemm<WithBF<CfgNarrow>::type, A_KC, B_NC, false, EpiStore>(c->s, g, EpiStore{dX0, d.E, 0})));
+        else NVQA_HIP((launch_gemm<CfgNarrow, A_KC, B_NC, false, EpiStore>(c->s, g, EpiStore{dX0, d.E, 0})));
+        return 0;
+    }
     NVQA_TRY((gemm_big<A_KC, B_NC>(c, g, EpiStore{dX0, d.E, 0})));
     return 0;
 }

@@ -31,6 +31,9 @@ template <int AM, int BMo> void sweep(const char *name, int M, int N, int K)
     T_(32, 128, 128, 32, 2, 2, 1, 1)    // BIG
     T_(16, 128, 128, 32, 4, 2, 1, 1)    // mf16 128x128 4x2
     T_(16, 128, 64, 32, 4, 2, 1, 1)     // mf16 128x64 4x2
+    T_(16, 32, 64, 32, 2, 2, 1, 1)      // mf16 32x64 2x2 (4 waves 16x32)
+    T_(16, 32, 64, 32, 2, 2, 2, 1)      // mf16 32x64 2x2 wk2 (8 waves)
+    T_(16, 64, 32, 32, 4, 2, 1, 1)      // mf16 64x32 4x2 (8 waves 16x16)
     printf("\n");
 }
 int main()
@@ -40,7 +43,7 @@ int main()
     std::vector<float> h(n);
     for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u) >> 9) * (1.0f / 8388608.f) - 0.5f;
     hipMemcpy(dA, h.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), n * 4, hipMemcpyHostToDevice);
-    printf("%-44s %-24s%-24s%-24s%-24s%-24s%-24s\n", "shape (M x N x K), layout", "MED mf32 64x64 pf2", "mf16 64x64 wk2", "mf16 64x64 4x2", "BIG mf32 128x128", "mf16 128x128 4x2", "mf16 128x64 4x2");
+    printf("%-44s %-24s%-24s%-24s%-24s%-24s%-24s\n", "shape (M x N x K), layout", "MED mf32 64x64 pf2", "mf16 64x64 wk2", "mf16 64x64 4x2", "BIG mf32 128x128", "mf16 128x128 4x2", "mf16 128x64 4x2"); printf("  (+ mf16 32x64 2x2, 32x64 2x2 wk2, 64x32 4x2)\n");
     sweep<A_MC, B_NC>("dW_o  1000 x 1024 x 512   MC/NC", 1000, 1024, 512);
     sweep<A_KC, B_NC>("dzd   512 x 1024 x 1000   KC/NC", 512, 1024, 1000);
     sweep<A_MC, B_NC>("dW_q  1024 x 2048 x 512   MC/NC", 1024, 2048, 512);
