@@ -439,7 +439,7 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
 {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int ks = 1;
-    while (ks < 8 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2;
+    while (ks < 16 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2; // tools/kbench11: 2048 x 200 x 13312: 16 slices 115 us, 8 slices 129 us
     if ((size_t)ks * M * N > c->slab_floats) ks = std::max<int>(1, (int)(c->slab_floats / ((size_t)M * N)));
     int kslice = (K + ks - 1) / ks;
     kslice = (kslice + 31) / 32 * 32;

@@ -40,6 +40,10 @@ void shape(int M, int N, int K)
     line<Cfg<32, 256, 128, 32, 4, 2, 1, 1>>("mf32 256x128x32 8w 4x2", M, N, K);
     line<Cfg<32, 128, 256, 32, 2, 4, 1, 1>>("mf32 128x256x32 8w 2x4", M, N, K);
     line<Cfg<32, 64, 64, 32, 2, 2, 1, 1>>("mf32 64x64x32 4w", M, N, K);
+    line<Cfg<16, 64, 32, 32, 4, 2, 1, 1>>("mf16 64x32x32 8w 4x2", M, N, K);
+    line<Cfg<32, 128, 32, 32, 4, 1, 1, 1>>("mf32 128x32x32 4w 4x1", M, N, K);
+    line<Cfg<16, 128, 32, 32, 4, 2, 1, 1>>("mf16 128x32x32 8w 4x2", M, N, K);
+    line<Cfg<32, 128, 32, 64, 4, 1, 1, 1>>("mf32 128x32x64 4w 4x1", M, N, K);
 }
 int main()
 {
