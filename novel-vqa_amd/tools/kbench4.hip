@@ -55,5 +55,9 @@ int main()
     L_("128 rows x 16 units, BK32, wk2 pf1 (256 blk)", 16, 128, 64, 32, 8, 1, 2, 1)
     L_("32 rows x 16 units, BK64, wk4 pf1 (1024 blk)", 16, 32, 64, 64, 2, 1, 4, 1)
     L_("32 rows x 16 units, BK32, wk2 pf1 (1024 blk)", 16, 32, 64, 32, 2, 1, 2, 1)
+    L_("64 rows x 16 units, BK128, wk2 pf1 (512 blk)", 16, 64, 64, 128, 4, 1, 2, 1)
+    L_("64 rows x 16 units, BK128, wk4 pf1 (512 blk)", 16, 64, 64, 128, 4, 1, 4, 1)
+    L_("64 rows x 16 units, BK64, wk2 pf2 (512 blk)", 16, 64, 64, 64, 4, 1, 2, 2)
+    L_("32 rows x 16 units, BK128, wk4 pf1 (1024 blk)", 16, 32, 64, 128, 2, 1, 4, 1)
     return 0;
 }
