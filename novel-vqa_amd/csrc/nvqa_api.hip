@@ -764,7 +764,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(lstm_dx0(c, dX0));
     {
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
-        const int waves = 8;
+        const int waves = 4; // arch1 tokens spread over the vocabulary: 4 scanning waves (32 KB of LDS, 4 workgroups per CU) beat 8
         const int blocks = (V + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
         hipLaunchKernelGGL(k_emb_bwd, dim3(blocks, (E + NVQA_EB_COLS - 1) / NVQA_EB_COLS), dim3(64 * waves),
                            (size_t)waves * NVQA_EB_ROWS * NVQA_EB_COLS * sizeof(float), c->s,
