@@ -470,7 +470,12 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
-    {   // layer 0: time-batched input projection + both biases (LSTM.lua:41-43), off the chain
+    // Layer 0 takes W_i2h x_t as a first K segment inside the level kernel, like the layers above it: the
+    // time-batched projection (0.128 ms, a 109 MB write and its re-read by the level epilogues) costs more than
+    // the 0.074 ms the extra K = E adds to the 27 levels, and the two layers' workgroups become closer in length
+    // (12 vs 16 K-tiles instead of 8 vs 16).  NVQA_FOLD_I2H=0 restores the batched projection (A/B runs).
+    static const bool fold0 = [] { const char *e = getenv("NVQA_FOLD_I2H"); return !(e && e[0] == '0'); }();
+    if (!fold0) {   // layer 0: time-batched input projection + both biases (LSTM.lua:41-43), off the chain
         const int in = d.E;
         ProfScope ps(c, PF_GEMM_I2H, 2.0 * TB * 4 * R * in, ((double)TB * (in + 4 * R) + 4.0 * R * in) * 4);
         GemmArgs g = mkargs(c->X0, in, c->P + c->lo.w_i2h[0], in, TB, 4 * R, in);
@@ -498,8 +503,8 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
             e.c = c->Cs[l] + (size_t)(t + 1) * B * R;
             e.h = c->Hs[l] + (size_t)(t + 1) * B * R;
             e.u_next = l + 1 < L ? c->U[l + 1] + (size_t)t * B * R : nullptr;
-            e.bias1 = l == 0 ? nullptr : c->P + c->lo.b_i2h[l];
-            e.bias2 = l == 0 ? nullptr : c->P + c->lo.b_h2h[l];
+            e.bias1 = l == 0 && !fold0 ? nullptr : c->P + c->lo.b_i2h[l];
+            e.bias2 = l == 0 && !fold0 ? nullptr : c->P + c->lo.b_h2h[l];
             e.nrows = c->nrows + t;
             e.sort_idx = c->sort_idx;
             e.R = R; e.B = B; e.T = TS; e.t = t; e.lnext_m1 = l;
@@ -508,10 +513,10 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
             // segment 1: Dropout(h^{l-1}_t) x W_i2h^T (layers >= 1; layer 0 reads the batched projection)
             // segment 2: h^l_{t-1} x W_h2h^T (absent at step 0: h_{-1} = 0)
             GemmArgs &g = ma.g[np];
-            if (l == 0) g = mkargs(c->X0, d.E, c->P + c->lo.w_i2h[0], d.E, B, R, 0, 0, R, c->nrows + t);
+            if (l == 0) g = mkargs(c->X0 + (size_t)t * B * d.E, d.E, c->P + c->lo.w_i2h[0], d.E, B, R, fold0 ? d.E : 0, 0, R, c->nrows + t);
             else g = mkargs(c->U[l] + (size_t)t * B * R, R, c->P + c->lo.w_i2h[l], R, B, R, R, 0, R, c->nrows + t);
             g.A2 = hprev; g.lda2 = R; g.B2 = c->P + c->lo.w_h2h[l]; g.ldb2 = R; g.K2 = t == 0 ? 0 : R;
-            const double kk = (l == 0 ? 0 : R) + (t == 0 ? 0 : R);
+            const double kk = (l == 0 ? (fold0 ? d.E : 0) : R) + (t == 0 ? 0 : R);
             flops += 2.0 * B * 4 * R * kk;
             bytes += ((double)B * kk + 4.0 * R * kk + (double)B * 4 * R * 2) * 4;
             ++np;
