@@ -22,7 +22,8 @@ GROUPS = [
     # i2h forward and the classifier's W_o product share a kernel (EpiBias2, K-contiguous x K-contiguous): the
     # time-batched one is the launch with more than a million threads
     ("gemm_i2h_fwd", lambda n, grid=0: "gemm_f32_kernel" in n and "EpiBias2" in n and grid > (1 << 20)),
-    ("gemm_dgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 0, 1, false" in n and "EpiStore" in n),
+    # d(input): the one K-contiguous x N-contiguous product with a plain store and a time-batched grid
+    ("gemm_dgrad", lambda n, grid=0: "gemm_f32_kernel" in n and ", 0, 1, false" in n and "EpiStore" in n and grid > 500000),
     ("rmsprop", lambda n: "k_rmsprop" in n),
     ("emb_bwd", lambda n: "k_emb_bwd" in n),
     ("emb_fwd", lambda n: "k_emb_fwd" in n),
