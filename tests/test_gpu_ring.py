@@ -28,8 +28,8 @@ def _run(pkg, d, params, batch, dr, ring):
 
 
 @pytest.mark.parametrize("kw", [
-    dict(arch=1, B=96, T=7, V=50, E=24, R=64, L=2, I=32, C=48, A=12),
-    dict(arch=1, B=70, T=5, V=50, E=16, R=32, L=3, I=32, C=16, A=12),
+    dict(arch=1, B=96, T=7, V=50, E=32, R=64, L=2, I=32, C=48, A=12),   # E, R multiples of 32: the ring kernel takes every level
+    dict(arch=1, B=70, T=5, V=50, E=16, R=32, L=3, I=32, C=16, A=12),   # E = 16: forward levels fall back (K % 32), BPTT levels on the ring
     dict(arch=2, B=80, T=6, V=50, E=64, R=64, L=2, I=32, C=8, A=12),
 ])
 def test_ring_levels_match_oracle_and_default_path(pkg, orc, kw):
