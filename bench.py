@@ -111,11 +111,23 @@ def main():
                          "(operands rounded to bf16, f32 accumulate); the headline metric is the f32 run")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU) and starts
+        # the N ranks as children under torch.distributed.run, exactly as the driver does
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     dist = None
@@ -129,11 +141,17 @@ def main():
     pkg = ge.load_package()
     w = WORKLOAD if args.arch == 1 else WORKLOAD_ARCH2
     dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
-    tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123)
+    try:
+        # rank: own sample ids and own dropout masks per rank; the parameter seed is common to all ranks
+        tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123, rank=rank)
+    except pkg.binding.NvqaError as e:
+        print(f"bench.py rank {rank}/{world}: nvqa_create failed: {e}", file=sys.stderr, flush=True)
+        if dist:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     tr.init_params()  # same on every rank (counter-based)
     if args.bf16:
         tr.ctx.set_precision(1)
-    tr.rng = np.random.default_rng(123 + 1000 * rank)  # each rank draws its own sample ids
     tr.load_dataset(*synth_dataset(w, 123, args.ragged), img_norm=True)
     if world > 1:
         ids = [tr.ctx.comm_unique_id() if rank == 0 else None]

@@ -134,6 +134,20 @@ int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
  * ABI stay f32 (SURVEY.md 8b "numerics contract").  Default 0 = the reference's f32 arithmetic
  * (torch.setdefaulttensortype('torch.FloatTensor'), 002_train_baseline.lua:54). */
 int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
+/* arch2 only: reproduce, on request, two things the reference's nn.Encoder does that are artefacts of its Lua code
+ * (flags = OR of the bits; default 0 = the model as designed):
+ *  NVQA_QUIRK_H0      misc/Encoder_lstm.lua:238-239 with :30-47,:164 -- backward aliases the table of initial-state
+ *                     tensors and stores gradOutput in its last slot, so from the second iteration on (training and
+ *                     validation forwards alike) the top layer starts from h0 = dL/d(encoder output) of the previous
+ *                     backward, and the step-1 weight gradient of the top layer's W_h2h is taken against the CURRENT
+ *                     step's dL/d(encoder output).
+ *  NVQA_QUIRK_LOOKUP  misc/Encoder_lstm.lua:49-58 with 002_train_baseline.lua:186,273 -- getParameters() runs before
+ *                     createClones(), whose lookup-table clones share the weight but not gradWeight with the flattened
+ *                     module: the lookup slice of encoder_dw_q stays zero, W_lk only sees weightDecay.
+ * Setting the flags also clears the carried h0 state. */
+#define NVQA_QUIRK_H0 1
+#define NVQA_QUIRK_LOOKUP 2
+int nvqa_set_ref_quirks(nvqa_ctx *ctx, int flags);
 /* Per-segment gradient scale applied before the clamp: {lr_scale, lr_scale, 1} reproduces
  * -lr_scale of 003_train_ae_based_wp.lua:30,344. */
 int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);

@@ -436,10 +436,11 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
 // token t-2 with null (0) rewritten to token 1 (:197).  It stops at the first all-null time
 // row (:185-189): tmax = number of steps run.  One workgroup.
 // ---------------------------------------------------------------------------------
+#define NVQA_ARCH2_TMAX 256
 __global__ void k_arch2_tmax(const int32_t *tok, int B, int T, int32_t *nrows /*[T+2]*/, int32_t *tinfo /*[2]: tmax, tmax-1*/,
                              int32_t *sort_idx, int32_t *sort_inv)
 {
-    __shared__ int colany[256];
+    __shared__ int colany[NVQA_ARCH2_TMAX]; // T <= NVQA_ARCH2_TMAX is checked by nvqa_create
     for (int t = threadIdx.x; t < T; t += blockDim.x) colany[t] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < B * T; i += blockDim.x)

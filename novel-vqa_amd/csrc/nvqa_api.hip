@@ -159,8 +159,13 @@ static void comm_destroy(nvqa_ctx *c); // with the RCCL loader, below
 // ------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------
+static int g_alloc_count = 0, g_alloc_fail = -1;
 template <class T> static int dalloc(T **p, size_t n)
 {
+    if (g_alloc_fail >= 0 && g_alloc_count++ == g_alloc_fail) {
+        set_error("hipMalloc of %zu bytes failed: injected by NVQA_FAIL_ALLOC", std::max<size_t>(n, 1) * sizeof(T));
+        return -1;
+    }
     NVQA_HIP(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
     return 0;
 }
@@ -179,8 +184,20 @@ static int check_dims(const nvqa_dims *d)
                   d->I, d->C, d->A);
         return -1;
     }
+    // single-workgroup batch assembly kernels keep per-step / per-row tables in LDS (kernels.h)
+    if (d->arch == NVQA_ARCH2 && d->T > NVQA_ARCH2_TMAX) {
+        set_error("arch2: T=%d exceeds the %d question steps k_arch2_tmax supports", d->T, NVQA_ARCH2_TMAX);
+        return -1;
+    }
+    if (d->arch == NVQA_ARCH1 && (2 * ((size_t)d->T + 1) + (size_t)d->B) * sizeof(int) > 64 * 1024) {
+        set_error("arch1: B=%d, T=%d need %zu bytes of LDS in k_sort_lengths (limit 65536)", d->B, d->T,
+                  (2 * ((size_t)d->T + 1) + (size_t)d->B) * sizeof(int));
+        return -1;
+    }
     return 0;
 }
+
+static int create_impl(nvqa_ctx *c);
 
 extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
 {
@@ -198,6 +215,25 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     c->d = *dims;
     c->device = device;
     if (nvqa_layout_init(dims, &c->lo)) { delete c; set_error("layout"); return -1; }
+    const int rc = create_impl(c);
+    if (rc != 0) { // a failure half-way (out of memory, ...) releases whatever was acquired; the message survives
+        const std::string keep = nvqa_last_error();
+        nvqa_destroy(c);
+        set_error("%s", keep.c_str());
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+// NVQA_FAIL_ALLOC=n makes the n-th device allocation of nvqa_create fail (tests: the failure path frees the context)
+static int create_impl(nvqa_ctx *c)
+{
+    {
+        const char *e = getenv("NVQA_FAIL_ALLOC");
+        g_alloc_fail = e ? atoi(e) : -1;
+        g_alloc_count = 0;
+    }
     const nvqa_dims &d = c->d;
     c->TS = d.arch == NVQA_ARCH1 ? d.T : d.T + 2;
     const size_t B = d.B, R = d.R, E = d.E, L = d.L, TS = c->TS, TB = TS * B;
@@ -244,6 +280,8 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     }
     NVQA_TRY(dalloc(&c->dCT, L * B * R));
     NVQA_TRY(dalloc(&c->dHT, L * B * R));
+    NVQA_HIP(hipMemsetAsync(c->dCT, 0, L * B * R * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->dHT, 0, L * B * R * 4, c->s)); // NVQA_QUIRK_H0 reads it before the first backward
     const size_t Q = d.arch == NVQA_ARCH1 ? 2 * R * L : R, C = d.arch == NVQA_ARCH1 ? d.C : 0;
     NVQA_TRY(dalloc(&c->qd, B * Q));
     NVQA_TRY(dalloc(&c->vd, B * d.I));
@@ -265,6 +303,8 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * B * R));
     {   // LDS-DMA ring level kernels (gemm_ring.h): opt-in with NVQA_RING=1.  Measured equal to the
         // register-staged kernels within +-4 % (tools/kbench6, kbench9), so they are not the default.
+        const char *ef = getenv("NVQA_FOLD_I2H");
+        c->fold_i2h = !(ef && ef[0] == '0');
         const char *env = getenv("NVQA_RING");
         c->use_ring = env && env[0] == '1' && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
         if (c->use_ring) NVQA_TRY(dalloc(&c->WT, (size_t)L * 2 * 4 * R * R));
@@ -272,7 +312,6 @@ extern "C" int nvqa_create(const nvqa_dims *dims, int device, nvqa_ctx **out)
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
     NVQA_HIP(hipStreamSynchronize(c->s));
-    *out = c;
     return 0;
 }
 
@@ -474,7 +513,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
     // time-batched projection (0.128 ms, a 109 MB write and its re-read by the level epilogues) costs more than
     // the 0.074 ms the extra K = E adds to the 27 levels, and the two layers' workgroups become closer in length
     // (12 vs 16 K-tiles instead of 8 vs 16).  NVQA_FOLD_I2H=0 restores the batched projection (A/B runs).
-    static const bool fold0 = [] { const char *e = getenv("NVQA_FOLD_I2H"); return !(e && e[0] == '0'); }();
+    const bool fold0 = c->fold_i2h; // NVQA_FOLD_I2H, read at nvqa_create
     if (!fold0) {   // layer 0: time-batched input projection + both biases (LSTM.lua:41-43), off the chain
         const int in = d.E;
         ProfScope ps(c, PF_GEMM_I2H, 2.0 * TB * 4 * R * in, ((double)TB * (in + 4 * R) + 4.0 * R * in) * 4);
@@ -515,8 +554,10 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
             GemmArgs &g = ma.g[np];
             if (l == 0) g = mkargs(c->X0 + (size_t)t * B * d.E, d.E, c->P + c->lo.w_i2h[0], d.E, B, R, fold0 ? d.E : 0, 0, R, c->nrows + t);
             else g = mkargs(c->U[l] + (size_t)t * B * R, R, c->P + c->lo.w_i2h[l], R, B, R, R, 0, R, c->nrows + t);
-            g.A2 = hprev; g.lda2 = R; g.B2 = c->P + c->lo.w_h2h[l]; g.ldb2 = R; g.K2 = t == 0 ? 0 : R;
-            const double kk = (l == 0 ? (fold0 ? d.E : 0) : R) + (t == 0 ? 0 : R);
+            // h_{-1} = 0: no recurrent product at step 0 -- except under NVQA_QUIRK_H0, where the top layer's h0 is live
+            const bool h0_live = t > 0 || (d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) && l == L - 1);
+            g.A2 = hprev; g.lda2 = R; g.B2 = c->P + c->lo.w_h2h[l]; g.ldb2 = R; g.K2 = h0_live ? R : 0;
+            const double kk = (l == 0 ? (fold0 ? d.E : 0) : R) + (h0_live ? R : 0);
             flops += 2.0 * B * 4 * R * kk;
             bytes += ((double)B * kk + 4.0 * R * kk + (double)B * 4 * R * 2) * 4;
             ++np;
@@ -803,6 +844,8 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
         hipLaunchKernelGGL(k_arch2_embed, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->tinfo, c->P + c->lo.w_lk, B, T, d.V, E, c->X0, c->ptok);
     }
     NVQA_HIP(hipGetLastError());
+    if (c->quirks & NVQA_QUIRK_H0) // top-layer h0 = what the last backward left in the aliased tensor (Encoder_lstm.lua:238-239)
+        NVQA_HIP(hipMemcpyAsync(c->Hs[L - 1], c->dHT + (size_t)(L - 1) * B * R, (size_t)B * R * 4, hipMemcpyDeviceToDevice, c->s));
     NVQA_TRY(lstm_forward(c, dr));
     {
         ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * R * 4);
@@ -838,6 +881,8 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, R, B, R, A),
                                        EpiHead2{c->dHT + (size_t)(L - 1) * B * R, R, dr})));
     }
+    if (c->quirks & NVQA_QUIRK_H0) // the aliased h0 tensor now holds THIS step's gradient: the step-1 dW_h2h sees it
+        NVQA_HIP(hipMemcpyAsync(c->Hs[L - 1], c->dHT + (size_t)(L - 1) * B * R, (size_t)B * R * 4, hipMemcpyDeviceToDevice, c->s));
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
     NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr));
@@ -848,7 +893,9 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     }
     NVQA_TRY(colsum(c, c->dX0, B, E, E, G + c->lo.b_p, nullptr));
     NVQA_TRY(reduce_segment(c, 0)); // cnn projection
-    {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
+    if (c->quirks & NVQA_QUIRK_LOOKUP) { // the reference's flat gradient never receives the lookup gradient: zeros, nothing to exchange
+        NVQA_HIP(hipMemsetAsync(G + c->lo.w_lk, 0, (size_t)(V + 1) * E * 4, c->s));
+    } else {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
         ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)(V + 1) * E) * 4);
         const int waves = 8;
         const int blocks = (V + 1 + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
@@ -857,7 +904,8 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
                            c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
     }
     NVQA_HIP(hipGetLastError());
-    NVQA_TRY(reduce_range(c, c->lo.w_lk, (size_t)(V + 1) * E, 1)); // lookup table: travels under the weight-gradient GEMMs
+    if (!(c->quirks & NVQA_QUIRK_LOOKUP))
+        NVQA_TRY(reduce_range(c, c->lo.w_lk, (size_t)(V + 1) * E, 1)); // lookup table: travels under the weight-gradient GEMMs
     for (int l = L - 1; l >= 0; --l) NVQA_TRY(lstm_wgrads(c, l));  // + each layer's slice of the encoder segment
     return 0;
 }
@@ -989,6 +1037,20 @@ extern "C" int nvqa_set_fusion(nvqa_ctx *c, int askip)
 {
     if (!c || c->d.arch != NVQA_ARCH1 || (askip != 0 && askip != 1)) { set_error("nvqa_set_fusion: arch1 context and mode 0/1 expected"); return -1; }
     c->fusion_askip = askip;
+    return 0;
+}
+extern "C" int nvqa_set_ref_quirks(nvqa_ctx *c, int flags)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    if (c->d.arch != NVQA_ARCH2 || (flags & ~(NVQA_QUIRK_H0 | NVQA_QUIRK_LOOKUP))) {
+        set_error("nvqa_set_ref_quirks: arch2 context and flags within %d expected", NVQA_QUIRK_H0 | NVQA_QUIRK_LOOKUP);
+        return -1;
+    }
+    NVQA_HIP(hipSetDevice(c->device));
+    const size_t BR = (size_t)c->d.B * c->d.R;
+    NVQA_HIP(hipMemsetAsync(c->dHT, 0, (size_t)c->d.L * BR * 4, c->s));  // the carried h0 state
+    NVQA_HIP(hipMemsetAsync(c->Hs[c->d.L - 1], 0, BR * 4, c->s));        // and the step-0 rows it may have been copied into
+    c->quirks = flags;
     return 0;
 }
 extern "C" int nvqa_set_precision(nvqa_ctx *c, int bf16)
@@ -1124,6 +1186,7 @@ extern "C" int nvqa_step_indices(nvqa_ctx *c, const int64_t *qinds, const nvqa_d
 namespace {
 struct Id128 { char b[128]; }; // ncclUniqueId, passed by value
 struct Rccl {
+    std::string path;
     void *h = nullptr;
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, Id128, int) = nullptr;
@@ -1131,31 +1194,53 @@ struct Rccl {
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
-Rccl g_rccl;
-int load_rccl()
+// One table per library path.  NVQA_RCCL_LIB names the collective library to load instead of librccl.so (read at
+// every nvqa_comm_* call, so a process can hold contexts on different libraries): any .so that exports the five nccl*
+// symbols below.  tests/shim/nccl_shim.hip is one whose all-reduce returns world x send, i.e. what `world` ranks with
+// identical gradients produce, so the whole exchange path can be checked on one GPU (tests/test_gpu_dp_shim.py).
+std::vector<Rccl *> g_rccl_libs;
+const Rccl *load_rccl()
 {
-    if (g_rccl.h) return 0;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { set_error("cannot load librccl.so: %s", dlerror()); return -1; }
-    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
-    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
-    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
-    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { set_error("librccl.so lacks nccl symbols"); return -1; }
-    g_rccl.h = h;
-    return 0;
+    const char *env = getenv("NVQA_RCCL_LIB");
+    const std::string want = env && env[0] ? env : "";
+    for (const Rccl *r : g_rccl_libs)
+        if (r->path == want) return r;
+    void *h = nullptr;
+    if (!want.empty()) {
+        h = dlopen(want.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("cannot load NVQA_RCCL_LIB=%s: %s", want.c_str(), dlerror()); return nullptr; }
+    } else {
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { set_error("cannot load librccl.so: %s", dlerror()); return nullptr; }
+    }
+    Rccl *r = new Rccl();
+    r->path = want;
+    r->GetUniqueId = (decltype(r->GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r->CommInitRank = (decltype(r->CommInitRank))dlsym(h, "ncclCommInitRank");
+    r->AllReduce = (decltype(r->AllReduce))dlsym(h, "ncclAllReduce");
+    r->CommDestroy = (decltype(r->CommDestroy))dlsym(h, "ncclCommDestroy");
+    r->GetErrorString = (decltype(r->GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r->GetUniqueId || !r->CommInitRank || !r->AllReduce) {
+        set_error("%s lacks the nccl symbols", want.empty() ? "librccl.so" : want.c_str());
+        delete r;
+        return nullptr;
+    }
+    r->h = h;
+    g_rccl_libs.push_back(r);
+    return r;
 }
+inline const Rccl *rccl_of(const nvqa_ctx *c) { return static_cast<const Rccl *>(c->rccl); }
 } // namespace
 
 extern "C" int nvqa_comm_unique_id(void *id_out)
 {
     if (!id_out) { set_error("NULL argument"); return -1; }
-    NVQA_TRY(load_rccl());
-    const int rc = g_rccl.GetUniqueId(id_out);
-    if (rc) { set_error("ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    const Rccl *r = load_rccl();
+    if (!r) return -1;
+    const int rc = r->GetUniqueId(id_out);
+    if (rc) { set_error("ncclGetUniqueId: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
     return 0;
 }
 
@@ -1163,14 +1248,17 @@ extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
 {
     if (!c || !id) { set_error("NULL argument"); return -1; }
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world %d/%d", rank, world); return -1; }
+    if (c->comm) { set_error("nvqa_comm_init: the context already has a communicator"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
-    NVQA_TRY(load_rccl());
+    const Rccl *r = load_rccl();
+    if (!r) return -1;
     Id128 idv;
     memcpy(idv.b, id, 128);
     void *comm = nullptr;
-    const int rc = g_rccl.CommInitRank(&comm, world, idv, rank);
-    if (rc) { set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    const int rc = r->CommInitRank(&comm, world, idv, rank);
+    if (rc) { set_error("ncclCommInitRank: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
     c->comm = comm;
+    c->rccl = r;
     c->rank = rank;
     c->world = world;
     return 0;
@@ -1187,8 +1275,9 @@ static int reduce_range(nvqa_ctx *c, size_t off, size_t count, int ev)
     NVQA_HIP(hipEventRecord(c->evSeg[ev], c->s));
     NVQA_HIP(hipStreamWaitEvent(c->sc, c->evSeg[ev], 0));
     ProfScope ps(c, PF_ALLREDUCE, 0, 4.0 * count, c->sc);
-    const int rc = g_rccl.AllReduce(c->G + off, c->G + off, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
-    if (rc) { set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return -1; }
+    const Rccl *r = rccl_of(c);
+    const int rc = r->AllReduce(c->G + off, c->G + off, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
+    if (rc) { set_error("ncclAllReduce: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
     return 0;
 }
 static int reduce_segment(nvqa_ctx *c, int seg)
@@ -1199,8 +1288,9 @@ static int reduce_segment(nvqa_ctx *c, int seg)
 }
 static void comm_destroy(nvqa_ctx *c)
 {
-    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->comm && rccl_of(c) && rccl_of(c)->CommDestroy) rccl_of(c)->CommDestroy(c->comm);
     c->comm = nullptr;
+    c->rccl = nullptr;
 }
 static int reduce_join(nvqa_ctx *c)
 {

@@ -80,6 +80,7 @@ struct nvqa_ctx {
     // arch1 embedding table transposed to [V][E])
     float *P = nullptr, *G = nullptr, *M2 = nullptr;
     bool have_grads = false;
+    int quirks = 0;                   // nvqa_set_ref_quirks (arch2)
     int fusion_askip = 0;             // 0 netdef.AxB, 1 netdef.AskipB
     float gscale[3] = {1.f, 1.f, 1.f}; // per-segment gradient scale before the clamp (-lr_scale)
 
@@ -104,6 +105,7 @@ struct nvqa_ctx {
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
     float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
     bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate
+    bool fold_i2h = true;         // layer-0 input projection as a first K segment of the level kernel; NVQA_FOLD_I2H=0: separate time-batched GEMM
     bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
@@ -113,6 +115,7 @@ struct nvqa_ctx {
 
     // data parallel
     void *comm = nullptr;
+    const void *rccl = nullptr; // the collective library's entry points this communicator came from (nvqa_api.hip)
     int rank = 0, world = 1;
 
     // profiling

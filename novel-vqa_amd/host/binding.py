@@ -52,6 +52,7 @@ SYMBOLS = {
     "nvqa_rmsprop_update": (ctypes.c_int, [_vp] + [ctypes.c_float] * 5),
     "nvqa_set_fusion": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "nvqa_set_ref_quirks": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_set_grad_scales": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_dataset_load": (ctypes.c_int, [_vp, ctypes.c_int64, _i32p, _i32p, _i32p, _i32p,
                                          ctypes.c_int64, _f32p, ctypes.c_int]),
@@ -215,6 +216,12 @@ class Context:
 
     def set_fusion(self, askip):
         self._check(self.lib.nvqa_set_fusion(self._h, int(askip)))
+
+    QUIRK_H0, QUIRK_LOOKUP = 1, 2
+
+    def set_ref_quirks(self, flags):
+        """arch2: reproduce the reference's aliased-h0 / untrained-lookup artefacts (include/nvqa.h)."""
+        self._check(self.lib.nvqa_set_ref_quirks(self._h, int(flags)))
 
     def set_precision(self, bf16):
         self._check(self.lib.nvqa_set_precision(self._h, int(bool(bf16))))

@@ -23,7 +23,7 @@ DECAY_FACTOR = 0.99997592083  # 002_train_baseline.lua:78
 
 class VQATrainer:
     def __init__(self, dims, device=0, learning_rate=3e-4, alpha=0.99, epsilon=1e-8,
-                 weight_decay=None, clamp=10.0, seed=123, dropout_p=0.5, dropout=True):
+                 weight_decay=None, clamp=10.0, seed=123, dropout_p=0.5, dropout=True, rank=0):
         self.dims = dims
         self.ctx = binding.Context(dims, device)
         self.learningRate = learning_rate
@@ -31,11 +31,15 @@ class VQATrainer:
         # arch2 baseline sets optimize.weightDecay = 1e-4 (003_.../002_train_baseline.lua:197)
         self.weightDecay = (1e-4 if dims.arch == 2 else 0.0) if weight_decay is None else weight_decay
         self.seed = seed
+        # data parallel: parameters are initialised from `seed` on every rank (identical replicas), but each rank
+        # draws its own dropout masks -- ranks hold different samples, identical masks would correlate them
+        self.dropout_seed = seed + 1000 * rank
+        self.rank = rank
         self.iter = 0
         self.dropout_p = dropout_p
         self.dropout_on = dropout
         self.running_avg = None
-        self.rng = np.random.default_rng(seed)
+        self.rng = np.random.default_rng(seed + 1000 * rank)  # each rank draws its own sample ids
         self.n_questions = 0
 
     # -- parameters (join_vector({encoder_w_q, embedding_w_q, multimodal_w})) ---------------
@@ -49,7 +53,7 @@ class VQATrainer:
         return self.ctx.get_params()
 
     def _dropout(self):
-        return binding.Dropout(1 if self.dropout_on else 0, self.dropout_p, self.seed, self.iter)
+        return binding.Dropout(1 if self.dropout_on else 0, self.dropout_p, self.dropout_seed, self.iter)
 
     # -- dataset:next_batch() -------------------------------------------------------------------
     def load_dataset(self, questions, lengths, img_pos, answers, feats, img_norm=True):

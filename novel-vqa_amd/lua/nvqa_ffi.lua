@@ -31,6 +31,7 @@ int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t 
 int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
 int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
 int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
+int nvqa_set_ref_quirks(nvqa_ctx *ctx, int flags);
 int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);
 int nvqa_dataset_load(nvqa_ctx *ctx, int64_t n_q, const int32_t *questions, const int32_t *lengths,
                       const int32_t *img_pos, const int32_t *answers, int64_t n_img,

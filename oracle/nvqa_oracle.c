@@ -424,8 +424,40 @@ int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok
 /* arch2 (003_train_vqa_arch2): image-as-first-token encoder                  */
 /* ------------------------------------------------------------------------- */
 /* tok [B x T] LEFT-aligned, 0 = null (the reference's seq is its [T x B] transpose,
- * 002_train_baseline.lua:216).  Quirk Q1 (aliased init state) is NOT reproduced:
- * h0 = 0 (a fresh single step is unaffected). */
+ * 002_train_baseline.lua:216).
+ *
+ * Two things the reference's arch2 code does that its authors cannot have intended are reproduced only on request
+ * (oracle_set_ref_quirks; default 0 = the model as designed, a fresh single step is the same either way for Q1):
+ *
+ *  bit 0, Q1 "aliased init state" (misc/Encoder_lstm.lua:238-239 with :30-47 and :164).  updateGradInput does
+ *    `dstate_enc = {[tmax] = self.init_state_enc}; dstate_enc[tmax][num_state] = gradOutput`: the Lua TABLE of
+ *    initial-state tensors is aliased, so entry num_state = 2L (the top layer's h0, misc/LSTM_encoder.lua:11-14,54-55)
+ *    becomes the gradOutput tensor itself -- multimodal_net.gradInput, i.e. the nn.Dropout module's gradInput buffer.
+ *    _createInitState never re-zeroes it while the batch size stays the same.  Consequences, reproduced here:
+ *      - every forward after the first backward (training and validate() alike) starts the top layer from
+ *        h0 = dL/d(encoder output) as the LAST backward left it (dropout mask and 1/(1-p) included);
+ *      - inside a backward, that same tensor already holds the CURRENT step's gradient when the step-1 clone runs
+ *        accGradParameters, so dW_h2h of the top layer receives dgates_1^T x (current dL/dh), not the h0 the
+ *        forward pass used.  (The gradient flowing INTO h0 is discarded either way.)
+ *  bit 1, Q11 "lookup table never trained" (misc/Encoder_lstm.lua:49-58 with 002_train_baseline.lua:186,273).
+ *    encoder_model:getParameters() flattens self.lookup_table BEFORE createClones(); createClones builds
+ *    lookup_tables_encoder[1] = self.lookup_table:clone('weight') -- weight shared, gradWeight NOT -- and the later
+ *    clones share gradWeight with clone [1].  backward accumulates into the clones' gradWeight, which is not part
+ *    of encoder_dw_q: the lookup slice of the flat gradient is zeroed every iteration (:294) and never written, so
+ *    W_lk only ever sees weightDecay through RMSprop.  With this bit the lookup gradient is returned as zero. */
+#define ORACLE_QUIRK_H0 1
+#define ORACLE_QUIRK_LOOKUP 2
+static int g_quirks = 0;
+static real *g_h0 = NULL; /* the aliased tensor: survives between steps */
+static size_t g_h0_n = 0;
+void oracle_set_ref_quirks(int flags)
+{
+    g_quirks = flags;
+    free(g_h0);
+    g_h0 = NULL;
+    g_h0_n = 0;
+}
+
 int oracle_arch2_step(const nvqa_dims *d, const real *params, const int32_t *tok, const real *img,
                       const int32_t *labels, const nvqa_dropout *dr_in, int train, real *loss_out,
                       real *grads, real *scores_out, int32_t *argmax_out)
@@ -463,6 +495,14 @@ int oracle_arch2_step(const nvqa_dims *d, const real *params, const int32_t *tok
          *Dl = zalloc((size_t)L * tmax * SB), *tmp = zalloc((size_t)B * 4 * R);
 #define CS(l, i) (Cs + ((size_t)(l) * (tmax + 1) + (i)) * SB)
 #define HS(l, i) (Hs + ((size_t)(l) * (tmax + 1) + (i)) * SB)
+    if (g_quirks & ORACLE_QUIRK_H0) { /* Q1: top-layer h0 = what the last backward left in the aliased tensor */
+        if (g_h0_n != SB) { /* first use, or the batch size changed (:37-39 resize + zero) */
+            free(g_h0);
+            g_h0 = zalloc(SB);
+            g_h0_n = SB;
+        }
+        memcpy(HS(L - 1, 0), g_h0, sizeof(real) * SB);
+    }
     for (int i = 0; i < tmax; ++i)
         for (int l = 0; l < L; ++l) {
             const int in = l == 0 ? E : R;
@@ -507,6 +547,10 @@ int oracle_arch2_step(const nvqa_dims *d, const real *params, const int32_t *tok
         lin_bwd_dx(B, A, R, dscores, params + lo.w_o, dhd, 0);
         real *dC = zalloc((size_t)L * SB), *dH = zalloc((size_t)L * SB);
         for (size_t z = 0; z < SB; ++z) dH[(size_t)(L - 1) * SB + z] = Dh[z] * dhd[z];
+        if (g_quirks & ORACLE_QUIRK_H0) { /* Q1: the aliased h0 tensor now IS this gradient (see above) */
+            memcpy(g_h0, dH + (size_t)(L - 1) * SB, sizeof(real) * SB);
+            memcpy(HS(L - 1, 0), g_h0, sizeof(real) * SB);
+        }
         real *da = zalloc((size_t)B * 4 * R), *du = zalloc((size_t)B * (R > E ? R : E)),
              *dcp = zalloc(SB), *dhp = zalloc(SB);
         for (int i = tmax - 1; i >= 0; --i)
@@ -528,7 +572,7 @@ int oracle_arch2_step(const nvqa_dims *d, const real *params, const int32_t *tok
                 } else if (i == 0) {
                     /* dx_1 -> cnn_projection:backward (:321-322) */
                     lin_bwd_dw(B, E, I, du, img, grads + lo.w_p, grads + lo.b_p);
-                } else {
+                } else if (!(g_quirks & ORACLE_QUIRK_LOOKUP)) {
                     /* LookupTable accGradParameters into the shared gradWeight (Encoder_lstm.lua:256) */
                     real *gW = grads + lo.w_lk;
                     for (int b = 0; b < B; ++b) {

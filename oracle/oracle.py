@@ -144,6 +144,13 @@ class Oracle:
         """0 = netdef.AxB, 1 = netdef.AskipB (process-wide switch of the oracle library)."""
         self.lib.oracle_set_fusion(int(askip))
 
+    QUIRK_H0, QUIRK_LOOKUP = 1, 2
+
+    def set_ref_quirks(self, flags):
+        """arch2 reference quirks (nvqa_oracle.c, above oracle_arch2_step): 1 = Q1 aliased top-layer h0,
+        2 = Q11 lookup table receives no gradient.  Process-wide; also forgets the carried h0 state."""
+        self.lib.oracle_set_ref_quirks(int(flags))
+
     def set_precision(self, bf16):
         """1 = every operand of a dense product rounded to bf16 first (nvqa_set_precision); process-wide."""
         self.lib.oracle_set_precision(int(bool(bf16)))

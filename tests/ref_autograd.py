@@ -129,7 +129,19 @@ def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True
     return {"loss": float(loss.detach()), "scores": scores.detach().numpy(), "grads": grads}
 
 
-def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True):
+class AliasedH0:
+    """The tensor that misc/Encoder_lstm.lua:238-239 aliases (quirk Q1): slot 2L of init_state_enc becomes
+    multimodal_net.gradInput after the first backward and is never re-zeroed (:30-47).  `value` is what a
+    forward pass reads as the top layer's h0."""
+
+    def __init__(self, B, R):
+        self.value = torch.zeros(B, R, dtype=torch.float64)
+
+
+def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True, aliased_h0=None, no_lookup_grad=False):
+    """aliased_h0: an AliasedH0 carried across calls reproduces quirk Q1 with autograd plus the one correction its
+    mechanics imply (the step-1 clone's accGradParameters reads the tensor AFTER multimodal_net:backward rewrote
+    it).  no_lookup_grad: quirk Q11, the lookup slice of the flat gradient stays zero."""
     d = dims
     B, T, V, E, R, L, I, A = d.B, d.T, d.V, d.E, d.R, d.L, d.I, d.A
     TS = T + 2
@@ -141,6 +153,11 @@ def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True):
     v = torch.tensor(np.asarray(img, np.float64).reshape(B, I))
     c = [torch.zeros(B, R, dtype=torch.float64) for _ in range(L)]
     h = [torch.zeros(B, R, dtype=torch.float64) for _ in range(L)]
+    h0_old = None
+    if aliased_h0 is not None:
+        h0_old = aliased_h0.value.clone()
+        h[L - 1] = h0_old
+    a_top_first = None
     Dl = [None] + [drop_scales(drr, 1, (B, TS, R), lambda b, t, j, l=l: (((l - 1) * B + b) * TS + t) * R + j)
                    for l in range(1, L)]
     for t in range(1, TS + 1):
@@ -159,13 +176,30 @@ def arch2(dims, lo, params_np, tokens, img, labels, dr=None, train=True):
             u = x if l == 0 else Dl[l][:, t - 1, :] * h[l - 1]
             a = lin(u, p[f"w_i2h{l}"].view(4 * R, inn), p[f"b_i2h{l}"]) \
                 + lin(h[l], p[f"w_h2h{l}"].view(4 * R, R), p[f"b_h2h{l}"])
+            if t == 1 and l == L - 1 and train:
+                a.retain_grad()
+                a_top_first = a
             c[l], h[l] = _cell(a, c[l], R)
+    hfin = h[L - 1]
+    if train:
+        hfin.retain_grad()
     Dh = drop_scales(drr, 2, (B, R), lambda b, j: b * R + j)
-    scores = lin(Dh * h[L - 1], p["w_o"].view(A, R), p["b_o"])
+    scores = lin(Dh * hfin, p["w_o"].view(A, R), p["b_o"])
     y = torch.tensor(np.asarray(labels, np.int64) - 1)
     loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
     grads = None
     if train:
         loss.backward()
         grads = params.grad.numpy().copy()
+        if aliased_h0 is not None:
+            # multimodal_net:backward leaves dL/d(encoder output) in the aliased tensor BEFORE the encoder's backward
+            # runs; the step-1 nn.Linear(h2h) of the top layer then forms dW += dgates_1^T x (that tensor)
+            h0_new = hfin.grad.clone()
+            o, n = lo[f"w_h2h{L - 1}"]
+            corr = a_top_first.grad.t() @ (h0_new - h0_old)  # [4R x R]
+            grads[o:o + n] += corr.reshape(-1).numpy()
+            aliased_h0.value = h0_new
+        if no_lookup_grad:
+            o, n = lo["w_lk"]
+            grads[o:o + n] = 0.0
     return {"loss": float(loss.detach()), "scores": scores.detach().numpy(), "grads": grads}

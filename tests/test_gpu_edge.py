@@ -63,3 +63,25 @@ def test_short_eval_batch(pkg, orc):
     scores, argmax = ctx.forward(tok[:5], lens[:5], img[:5])   # n < B rows (last batch of a split)
     assert scores.shape == (5, d.A) and relmax(scores, ev["scores"][:5]) < 1e-4
     ctx.close()
+
+
+def test_create_failure_frees_the_context_and_bounds_are_checked(pkg, orc, monkeypatch):
+    """nvqa_create must not leak when an allocation fails half-way (NVQA_FAIL_ALLOC injects the n-th hipMalloc
+    failure), and dims that the single-workgroup assembly kernels cannot hold are rejected with a message."""
+    import torch
+    d = orc.make_dims(arch=1, B=64, T=8, V=50, E=64, R=256, L=2, I=1024, C=256, A=64)
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)   # warm: allocator pools exist
+    ctx.close()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for n in (0, 3, 11, 19, 27):
+        monkeypatch.setenv("NVQA_FAIL_ALLOC", str(n))
+        with pytest.raises(pkg.binding.NvqaError, match="NVQA_FAIL_ALLOC"):
+            pkg.binding.Context(gdims(pkg, d), 0)
+    monkeypatch.delenv("NVQA_FAIL_ALLOC")
+    assert free0 - torch.cuda.mem_get_info(0)[0] < (8 << 20), "device memory leaked by the failed creates"
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)   # and the library still works
+    ctx.close()
+    with pytest.raises(pkg.binding.NvqaError, match="arch2: T="):
+        pkg.binding.Context(gdims(pkg, orc.make_dims(arch=2, B=4, T=300, V=9, E=8, R=8, L=1, I=8, C=4, A=4)), 0)
+    with pytest.raises(pkg.binding.NvqaError, match="k_sort_lengths"):
+        pkg.binding.Context(gdims(pkg, orc.make_dims(arch=1, B=20000, T=6, V=9, E=8, R=8, L=1, I=8, C=8, A=4)), 0)

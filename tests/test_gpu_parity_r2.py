@@ -1,0 +1,163 @@
+"""Round-2 parity cases (VERDICT r1 "What's weak", parity 2-5), all through the C ABI against the f64 oracle:
+
+* the exact bench.py workload -- B = 512, ALL lengths 26, dropout on -- at full size;
+* a saturated regime (parameters x10..15: gates pinned at 0 / 1, decisive logits) where the argmax must be
+  bit-exact on every row, for arch1 and arch2;
+* logits element by element (|a-b| <= 1e-4 |b| + 2e-6), gradients per tensor in max-norm AND L2-norm;
+* two different batches in a row on ONE context (long questions, then short ones / another tmax): every stale
+  activation of step A that step B must not see (inactive rows of Gt/Hs/Cs/U/X0, skipped row tiles, skipped
+  K-tiles), under the default kernels, NVQA_FOLD_I2H=0 and NVQA_RING=1;
+* arch2's reference quirks (nvqa_set_ref_quirks) over three RMSprop iterations.
+Measured errors are appended to gpurun_out/parity_r02.jsonl; the tolerances below are ~10x those measurements."""
+import os
+
+import numpy as np
+import pytest
+
+from util import (assert_argmax_all_rows, assert_grads, assert_logits, gdims, gdrop, record, relmax)
+
+pytestmark = pytest.mark.gpu
+
+FULL1 = dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000)
+TOL_GRAD = 2e-5       # f32 MFMA chains vs f64: measured worst 1.6e-6 (init regime), see gpurun_out/parity_r02.jsonl
+TOL_GRAD_SAT = 2e-4   # saturated regime: K = 512..4096 sums of O(1) terms
+
+
+def _ctx(pkg, d, env=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        return pkg.binding.Context(gdims(pkg, d), 0)  # the switches are read at nvqa_create
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def _check_step(pkg, orc, d, ctx, params, batch, dr, tol, name, all_rows=False):
+    tok, lens, img, lab = batch
+    lens = lens if d.arch == 1 else None
+    o64 = orc.Oracle(np.float64)
+    ref = o64.step(d, params, tok, lens, img, lab, dr)
+    loss = ctx.step(tok, lens, img, lab, gdrop(pkg, dr) if dr is not None else None)
+    grads = ctx.get_grads()
+    el = abs(loss - ref["loss"]) / abs(ref["loss"])
+    assert el <= 2e-6, (loss, ref["loss"])
+    worst = assert_grads(orc, d, grads, ref["grads"], tol, name)
+    ev = o64.step(d, params, tok, lens, img, lab, None, train=False)
+    scores, argmax = ctx.forward(tok, lens, img)
+    e = assert_logits(scores, ev["scores"])
+    share = assert_argmax_all_rows(argmax, ev["scores"], ev["argmax"])
+    if all_rows:
+        assert share == 1.0, f"only {share:.3f} of the rows are decisive: the case is not in the saturated regime"
+    record(name, {"loss_rel": el, "grad_worst": worst, "logit_worst_x_tol": e, "decisive_rows": share,
+                  "max_abs_logit": float(np.abs(ev["scores"]).max())})
+    return ref
+
+
+def test_headline_workload_all_lengths_26_dropout_on(pkg, orc):
+    """What bench.py times: arch1, B=512, every question 26 tokens, dropout 0.5 on."""
+    d = orc.make_dims(**FULL1)
+    params = orc.synth_params(d)
+    batch = orc.synth_batch(d, full_length=True)
+    ctx = _ctx(pkg, d)
+    ctx.set_params(params)
+    _check_step(pkg, orc, d, ctx, params, batch, orc.Dropout(1, 0.5, 123, 7), TOL_GRAD, "headline_all26")
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,kw,scale", [
+    ("sat_arch1_mid", dict(arch=1, B=96, T=12, V=300, E=64, R=128, L=2, I=256, C=192, A=100), 12.0),
+    ("sat_arch1_full", FULL1, 10.0),
+    ("sat_arch2_mid", dict(arch=2, B=96, T=10, V=300, E=128, R=128, L=2, I=256, C=4, A=100), 12.0),
+    ("sat_arch2_full_L1", dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000), 10.0),
+])
+def test_saturated_regime_argmax_exact_on_every_row(pkg, orc, name, kw, scale):
+    d = orc.make_dims(**kw)
+    params = orc.synth_params(d) * np.float32(scale)
+    batch = orc.synth_batch(d, full_length=False, min_len=2)
+    ctx = _ctx(pkg, d)
+    ctx.set_params(params)
+    _check_step(pkg, orc, d, ctx, params, batch, orc.Dropout(1, 0.5, 123, 3), TOL_GRAD_SAT, name, all_rows=True)
+    ctx.close()
+
+
+SEQ_CASES = {
+    "arch1": dict(arch=1, B=96, T=9, V=80, E=32, R=64, L=2, I=64, C=48, A=24),
+    "arch2": dict(arch=2, B=80, T=8, V=80, E=64, R=64, L=2, I=64, C=8, A=24),
+}
+
+
+@pytest.mark.parametrize("env", [{}, {"NVQA_FOLD_I2H": "0"}, {"NVQA_RING": "1"}], ids=["default", "nofold", "ring"])
+@pytest.mark.parametrize("arch", ["arch1", "arch2"])
+def test_second_batch_on_a_used_context(pkg, orc, arch, env):
+    """Step A (long questions) then step B (short, other lengths / another tmax) on the same context: step B must
+    equal the oracle's single step on B -- nothing of A may leak through buffers B only partly rewrites."""
+    d = orc.make_dims(**SEQ_CASES[arch])
+    params = orc.synth_params(d)
+    tokA, lensA, imgA, labA = orc.synth_batch(d, seed=5, full_length=True)
+    tokB, lensB, imgB, labB = orc.synth_batch(d, seed=9, full_length=False)
+    if d.arch == 1:   # B: at most 4 tokens, so most time columns have few or no active rows
+        lensB = np.minimum(lensB, 1 + np.arange(d.B) % 4).astype(np.int32)
+        left = np.zeros_like(tokB)
+        rng = np.random.default_rng(1)
+        for b in range(d.B):
+            left[b, :lensB[b]] = rng.integers(1, d.V + 1, lensB[b])
+        tokB = orc.right_align(left, lensB)
+    else:             # B: every question ends after 3 tokens -> tmax = 5 of 10 steps
+        tokB[:, 3:] = 0
+    ctx = _ctx(pkg, d, env)
+    ctx.set_params(params)
+    for rep in range(2):  # A, B, A, B: also B's leftovers under A
+        _check_step(pkg, orc, d, ctx, params, (tokA, lensA, imgA, labA), orc.Dropout(1, 0.5, 123, 2 * rep), TOL_GRAD,
+                    f"seq_{arch}_A{rep}")
+        _check_step(pkg, orc, d, ctx, params, (tokB, lensB, imgB, labB), orc.Dropout(1, 0.5, 123, 2 * rep + 1), TOL_GRAD,
+                    f"seq_{arch}_B{rep}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("flags", [1, 2, 3])
+@pytest.mark.parametrize("L", [1, 2])
+def test_arch2_reference_quirks_over_three_iterations(pkg, orc, flags, L):
+    """nvqa_set_ref_quirks vs the oracle's switch (misc/Encoder_lstm.lua:238-239 aliased h0; :49-58 lookup table
+    without gradient): three JdJ + rmsprop iterations, the oracle restarted from the device parameters each time."""
+    d = orc.make_dims(arch=2, B=40, T=7, V=60, E=32, R=48, L=L, I=64, C=4, A=20)
+    params = orc.synth_params(d) * np.float32(8.0)   # large enough for dL/dh (the carried h0) to matter: 1e-2 of the gradient
+    tok, _, img, lab = orc.synth_batch(d, full_length=False)
+    o = orc.Oracle(np.float64)
+    ctx = _ctx(pkg, d)
+    ctx.set_params(params)
+    ctx.set_ref_quirks(flags)
+    o.set_ref_quirks(flags)
+    plain = orc.Oracle(np.float32)  # the f32 library holds the un-quirked result for the "it matters" check
+    try:
+        for it in range(3):
+            x = ctx.get_params()
+            dr = orc.Dropout(1, 0.5, 123, it)
+            ref = o.step(d, x, tok, None, img, lab, dr)
+            loss = ctx.step(tok, None, img, lab, gdrop(pkg, dr))
+            g = ctx.get_grads()
+            assert abs(loss - ref["loss"]) <= 2e-6 * abs(ref["loss"]), (it, loss, ref["loss"])
+            assert_grads(orc, d, g, ref["grads"], TOL_GRAD_SAT, f"quirks{flags}_L{L}_it{it}")
+            if flags & 1 and it > 0:
+                nq = plain.step(d, x, tok, None, img, lab, dr)
+                assert relmax(g, nq["grads"]) > 5 * TOL_GRAD_SAT, "the carried h0 must change the gradient measurably"
+            if flags & 2:
+                lo = orc.layout(d)["w_lk"]
+                assert np.all(g[lo[0]:lo[0] + lo[1]] == 0)
+            ctx.rmsprop_update(3e-3, 0.99, 1e-8, 1e-4, 10.0)
+        ev = o.step(d, ctx.get_params(), tok, None, img, lab, None, train=False)
+        scores, _ = ctx.forward(tok, None, img)     # validate(): evaluate mode reads the carried h0 too
+        assert_logits(scores, ev["scores"])
+        ctx.set_ref_quirks(0)                        # and it switches off: a clean h0 again
+        o.set_ref_quirks(0)
+        ev0 = o.step(d, ctx.get_params(), tok, None, img, lab, None, train=False)
+        scores0, _ = ctx.forward(tok, None, img)
+        assert_logits(scores0, ev0["scores"])
+    finally:
+        o.set_ref_quirks(0)
+    ctx.close()
