@@ -68,17 +68,24 @@ def test_short_eval_batch(pkg, orc):
 def test_create_failure_frees_the_context_and_bounds_are_checked(pkg, orc, monkeypatch):
     """nvqa_create must not leak when an allocation fails half-way (NVQA_FAIL_ALLOC injects the n-th hipMalloc
     failure), and dims that the single-workgroup assembly kernels cannot hold are rejected with a message."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime libnvqa itself is linked against (already loaded)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
     d = orc.make_dims(arch=1, B=64, T=8, V=50, E=64, R=256, L=2, I=1024, C=256, A=64)
     ctx = pkg.binding.Context(gdims(pkg, d), 0)   # warm: allocator pools exist
     ctx.close()
-    free0 = torch.cuda.mem_get_info(0)[0]
+    free0 = free_bytes()
     for n in (0, 3, 11, 19, 27):
         monkeypatch.setenv("NVQA_FAIL_ALLOC", str(n))
         with pytest.raises(pkg.binding.NvqaError, match="NVQA_FAIL_ALLOC"):
             pkg.binding.Context(gdims(pkg, d), 0)
     monkeypatch.delenv("NVQA_FAIL_ALLOC")
-    assert free0 - torch.cuda.mem_get_info(0)[0] < (8 << 20), "device memory leaked by the failed creates"
+    assert free0 - free_bytes() < (8 << 20), "device memory leaked by the failed creates"
     ctx = pkg.binding.Context(gdims(pkg, d), 0)   # and the library still works
     ctx.close()
     with pytest.raises(pkg.binding.NvqaError, match="arch2: T="):

@@ -30,32 +30,39 @@ def segment_errors(orc, d, got, ref):
 
 # ---- round-2 tolerances ---------------------------------------------------------------------------------------
 # north_star: "within 1e-4 relative on fp32 logits, bit-exact for argmax indices".  Logits are compared ELEMENT by
-# element: |a - b| <= 1e-4 |b| + ATOL_LOGIT, the absolute term covering logits that pass through zero (their f32
-# rounding noise is eps x the magnitude of the terms summed, not of the sum).
+# element: |a - b| <= 1e-4 |b| + 1e-5 max_row|b|.  The second term covers logits that pass through zero: a logit is a
+# sum of C products whose f32 rounding noise is eps x the magnitude of the TERMS (the same for every logit of a
+# row), not of the sum, so an element is held to 1e-4 of itself down to a tenth of its row's largest logit and to
+# 1e-5 of that largest logit below.
 RTOL_LOGIT = 1e-4
-ATOL_LOGIT = 2e-6
+RTOL_LOGIT_ROW = 1e-5
+
+
+def _logit_tol(b):
+    return RTOL_LOGIT * np.abs(b) + RTOL_LOGIT_ROW * np.abs(b).max(axis=1, keepdims=True)
 
 
 def logits_err(got, ref):
-    """max over elements of |a-b| / (RTOL_LOGIT |b| + ATOL_LOGIT): <= 1 passes."""
+    """max over elements of |a-b| / (1e-4 |b| + 1e-5 max_row|b|): <= 1 passes."""
     a = np.asarray(got, np.float64)
     b = np.asarray(ref, np.float64)
-    return float((np.abs(a - b) / (RTOL_LOGIT * np.abs(b) + ATOL_LOGIT)).max())
+    return float((np.abs(a - b) / _logit_tol(b)).max())
 
 
 def assert_logits(got, ref, scale=1.0):
     e = logits_err(got, ref)
-    assert e <= scale, f"logits: worst element at {e:.3g} x tolerance (|a-b| <= {RTOL_LOGIT}|b| + {ATOL_LOGIT})"
+    assert e <= scale, f"logits: worst element at {e:.3g} x tolerance (|a-b| <= 1e-4 |b| + 1e-5 max_row|b|), allowed {scale:.3g}"
     return e
 
 
-def assert_argmax_all_rows(argmax, ref_scores, ref_argmax):
-    """Bit-exact on every row whose top-2 gap exceeds what the logit tolerance could flip; returns the share of
-    such rows (callers of the saturated-regime tests require it to be 1.0)."""
+def assert_argmax_all_rows(argmax, ref_scores, ref_argmax, err_scale=1.0):
+    """Bit-exact on every row whose top-2 gap exceeds twice what the logit tolerance (x err_scale) could move;
+    returns the share of such rows."""
     s = np.asarray(ref_scores, np.float64)
     top2 = np.sort(s, 1)[:, -2:]
     gap = top2[:, 1] - top2[:, 0]
-    decisive = gap > 2 * (RTOL_LOGIT * np.abs(top2[:, 1]) + ATOL_LOGIT)
+    tol = (RTOL_LOGIT * np.abs(top2[:, 1]) + RTOL_LOGIT_ROW * np.abs(s).max(axis=1)) * err_scale
+    decisive = gap > 2 * tol
     assert np.array_equal(np.asarray(argmax)[decisive], np.asarray(ref_argmax)[decisive])
     return float(decisive.mean())
 
