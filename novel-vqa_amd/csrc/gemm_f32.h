@@ -701,7 +701,16 @@ template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
 __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_multi_kernel(MultiArgs<Epi> a)
 {
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (a.xcd) {
+    if (a.xcd == 2 && gridDim.z == 2 && gridDim.x % 4 == 0) {
+        // forward wavefront level with two layers in flight: XCD k = id % 8 owns (layer k / 4, quarter k % 4 of the
+        // unit tiles) for every row block, so that its L2 holds one layer's activations once and a quarter of that
+        // layer's weights (2 MB + 2 MB at R = 512) instead of both layers' activations and an eighth of both weights
+        const unsigned nx = gridDim.x, ny = gridDim.y;
+        const unsigned id = bx + nx * (by + ny * bz), k = id % 8, local = id / 8, qx = nx / 4;
+        bz = k / 4;
+        bx = (k % 4) * qx + local % qx;
+        by = local / qx;
+    } else if (a.xcd) {
         const unsigned nx = gridDim.x, ny = gridDim.y;
         const unsigned j = xcd_fold(bx + nx * (by + ny * bz), nx * ny * gridDim.z);
         bx = j % nx; by = (j / nx) % ny; bz = j / (nx * ny);

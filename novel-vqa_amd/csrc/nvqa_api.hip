@@ -17,6 +17,7 @@
 #include "gemm_f32.h"
 #include "gemm_ring.h"
 #include "kernels.h"
+#include "lstm_persist.h"
 #include "nvqa_ctx.h"
 
 using namespace nvqa;
@@ -309,6 +310,17 @@ static int create_impl(nvqa_ctx *c)
         c->use_ring = env && env[0] == '1' && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
         if (c->use_ring) NVQA_TRY(dalloc(&c->WT, (size_t)L * 2 * 4 * R * R));
     }
+    {   // persistent forward LSTM (lstm_persist.h): NVQA_PERSIST=1 opts in
+        const char *ep = getenv("NVQA_PERSIST");
+        c->persist_on = ep && ep[0] == '1';
+        hipDeviceProp_t prop;
+        NVQA_HIP(hipGetDeviceProperties(&prop, c->device));
+        c->num_cus = prop.multiProcessorCount;
+        c->pf_cnt_words = ((size_t)L * ((B + 63) / 64) * TS + 4 + 3) / 4 * 4; // counters for the finest row blocking + err word, 16-byte multiple
+        NVQA_TRY(dalloc(&c->pf_cnt, c->pf_cnt_words));
+        NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, sizeof(unsigned), hipHostMallocDefault));
+        *c->h_pf_err = 0;
+    }
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
     NVQA_HIP(hipStreamSynchronize(c->s));
@@ -335,6 +347,8 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
         if (c->U[l]) (void)hipFree(c->U[l]);
     }
     if (c->h_loss) (void)hipHostFree(c->h_loss);
+    if (c->h_pf_err) (void)hipHostFree(c->h_pf_err);
+    if (c->pf_cnt) (void)hipFree(c->pf_cnt);
     for (hipEvent_t e : {c->evComm, c->evStart})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evSeg)
@@ -345,12 +359,24 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     return 0;
 }
 
+// after the stream has drained: did a persistent-kernel wait give up? (lstm_persist.h: every spin is bounded)
+static int check_persist(nvqa_ctx *c)
+{
+    if (c->h_pf_err && *c->h_pf_err) {
+        set_error("persistent LSTM kernel: a workgroup timed out waiting for its neighbours (code 0x%x); results of that step are invalid", *c->h_pf_err);
+        *c->h_pf_err = 0;
+        c->persist_on = false; // later steps take the per-level path
+        return -3;
+    }
+    return 0;
+}
+
 extern "C" int nvqa_sync(nvqa_ctx *c)
 {
     if (!c) { set_error("ctx is NULL"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     NVQA_HIP(hipStreamSynchronize(c->s));
-    return 0;
+    return check_persist(c);
 }
 
 // ------------------------------------------------------------------------------------
@@ -505,10 +531,71 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
 // LSTM: shared by arch1 and arch2 (misc/LSTM.lua, misc/LSTM_encoder.lua have the same cell)
 // X0 [TS*B][E] holds the layer-0 inputs; nrows[t] rows are active at step t.
 // ------------------------------------------------------------------------------------
+// The whole forward unroll as one persistent, weight-stationary launch (lstm_persist.h).  Eligible shapes: the two the
+// reference trains (R = 512 with E = 200 [arch1] or E = 512 [arch2]) on a device with one CU per workgroup.
+template <int G0A, int GR, int MT>
+static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
+{
+    const size_t lds = std::max(PersistGeom<G0A, GR, MT>::LDS_BYTES, PersistGeom<GR, GR, MT>::LDS_BYTES);
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<G0A, GR, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_lstm_fwd_persist<G0A, GR, MT>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+static int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT), or 0 when the path does not apply
+{
+    const nvqa_dims &d = c->d;
+    if (!c->persist_on || c->bf16 || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
+    const int NU = d.R / 16;
+    for (int MT : {4, 8}) { // the smallest row block that still gives every workgroup its own CU
+        const int RB = (d.B + 16 * MT - 1) / (16 * MT);
+        if (d.L * RB * NU <= c->num_cus) return MT;
+    }
+    return 0;
+}
+
+static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, R = d.R, L = d.L, TS = c->TS;
+    PersistFwdArgs a = {};
+    for (int l = 0; l < L; ++l) {
+        a.Wi[l] = c->P + c->lo.w_i2h[l]; a.Wh[l] = c->P + c->lo.w_h2h[l];
+        a.bi[l] = c->P + c->lo.b_i2h[l]; a.bh[l] = c->P + c->lo.b_h2h[l];
+        a.U[l] = c->U[l]; a.Hs[l] = c->Hs[l]; a.Cs[l] = c->Cs[l]; a.Gt[l] = c->Gt[l];
+    }
+    a.X0 = c->X0; a.nrows = c->nrows; a.sort_idx = c->sort_idx;
+    a.B = B; a.R = R; a.E = d.E; a.L = L; a.TS = TS;
+    a.RB = (B + 16 * MT - 1) / (16 * MT); a.NU = R / 16;
+    a.h0_top = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) ? 1 : 0;
+    a.dr = dr;
+    a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
+    const int grid = L * a.RB * a.NU;
+    double flops = 0;
+    for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);
+    ProfScope ps(c, PF_LSTM_FWD, flops, 0);
+    NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s));
+    if (d.E == 200) {
+        if (MT == 4) NVQA_TRY((launch_persist_fwd<13, 32, 4>(c, a, grid)));
+        else NVQA_TRY((launch_persist_fwd<13, 32, 8>(c, a, grid)));
+    } else {
+        if (MT == 4) NVQA_TRY((launch_persist_fwd<32, 32, 4>(c, a, grid)));
+        else NVQA_TRY((launch_persist_fwd<32, 32, 8>(c, a, grid)));
+    }
+    NVQA_HIP(hipMemcpyAsync(c->h_pf_err, a.err, 4, hipMemcpyDeviceToHost, c->s));
+    return 0;
+}
+
 static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
+    if (const int MT = persist_rows(c)) return lstm_forward_persist(c, dr, MT);
     // Layer 0 takes W_i2h x_t as a first K segment inside the level kernel, like the layers above it: the
     // time-batched projection (0.128 ms, a 109 MB write and its re-read by the level epilogues) costs more than
     // the 0.074 ms the extra K = E adds to the 27 levels, and the two layers' workgroups become closer in length
@@ -563,6 +650,8 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
             ++np;
         }
         ProfScope ps(c, PF_LSTM_FWD, flops, bytes);
+        static const int fwd_map = [] { const char *e = getenv("NVQA_FWD_MAP"); return e ? atoi(e) : 0; }();
+        ma.xcd = fwd_map;
         bool ring = c->use_ring && !c->bf16;
         for (int i = 0; i < np && ring; ++i) ring = ring_ok(ma.g[i], true);
         if (ring) NVQA_HIP((launch_gemm_ring_multi<true, EpiLstmFwd, 1>(c->s, ma, np)));
@@ -929,6 +1018,7 @@ static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
     if (loss_out) {
         NVQA_HIP(hipStreamSynchronize(c->s));
         *loss_out = *c->h_loss;
+        NVQA_TRY(check_persist(c));
     }
     return 0;
 }
@@ -1027,6 +1117,7 @@ extern "C" int nvqa_forward(nvqa_ctx *c, int32_t n, const int32_t *tokens, const
         NVQA_TRY(arch2_forward(c, dr, false, true));
     }
     NVQA_HIP(hipStreamSynchronize(c->s));
+    NVQA_TRY(check_persist(c));
     if (scores_out) NVQA_HIP(hipMemcpy(scores_out, c->scores, (size_t)n * c->d.A * 4, hipMemcpyDeviceToHost));
     if (argmax_out) NVQA_HIP(hipMemcpy(argmax_out, c->argmax, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1074,7 +1165,7 @@ extern "C" int nvqa_get_loss(nvqa_ctx *c, float *loss_out)
     NVQA_HIP(hipSetDevice(c->device));
     NVQA_HIP(hipStreamSynchronize(c->s));
     *loss_out = *c->h_loss;
-    return 0;
+    return check_persist(c);
 }
 
 extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps, float wd, float clamp)

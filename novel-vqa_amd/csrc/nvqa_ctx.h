@@ -106,6 +106,11 @@ struct nvqa_ctx {
     float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
     bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate
     bool fold_i2h = true;         // layer-0 input projection as a first K segment of the level kernel; NVQA_FOLD_I2H=0: separate time-batched GEMM
+    bool persist_on = false;      // forward LSTM as one persistent weight-stationary launch (lstm_persist.h)
+    int num_cus = 0;
+    unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed before every launch)
+    size_t pf_cnt_words = 0;
+    unsigned *h_pf_err = nullptr; // pinned copy of the err word
     bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
