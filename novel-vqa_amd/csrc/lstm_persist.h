@@ -34,7 +34,8 @@ namespace nvqa {
 
 #define NVQA_PF_MAXL 4
 #define NVQA_PF_THREADS 256
-#define NVQA_PF_SPIN_LIMIT (1u << 23) // polls before a workgroup gives up (seconds)
+#define NVQA_PF_SPIN_LIMIT (1u << 21) // polls before a wave gives up (a few seconds); after the first give-up anywhere
+                                      // (err != 0) every other wait ends within 1024 polls: the launch drains
 
 struct PersistFwdArgs {
     const float *Wi[NVQA_PF_MAXL], *Wh[NVQA_PF_MAXL], *bi[NVQA_PF_MAXL], *bh[NVQA_PF_MAXL];
@@ -46,9 +47,16 @@ struct PersistFwdArgs {
     unsigned *cnt; // [L][RB][TS] arrival counters, zeroed before the launch
     unsigned *err; // != 0: a spin timed out (the launch still drains)
     int B, R, E, L, TS, RB, NU;
+    int dbg;       // measurement only (NVQA_PF_DBG): 1 no flag waits, 2 no cell math / stores, 8 activation loads without
+                   // memory traffic, 16 libdevice instead of hardware exp / rcp in the cell
     int h0_top;    // arch2 NVQA_QUIRK_H0: the top layer's h_{-1} (slice 0 of Hs) is live at step 0
     Drop dr;
 };
+
+// hardware exp2 / reciprocal forms of the gate non-linearities (v_exp_f32, v_rcp_f32: 1 ulp each): absolute error
+// ~1e-7 on values in [-1, 1], ~8 instructions instead of ~30 each; the cell epilogue is on every step's critical path
+__device__ __forceinline__ float pf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float pf_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));
@@ -70,6 +78,7 @@ __device__ __forceinline__ bool pf_wait_ge(unsigned *word, unsigned want, unsign
             __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         __builtin_amdgcn_s_sleep(4);
     }
 }
@@ -89,11 +98,10 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     typedef PersistGeom<G0, G1, MT> GE;
     static_assert(G1 % 4 == 0, "R must be a multiple of 64");
     static_assert(GE::NT % 2 == 0, "chunks per step must be even (static staging-register sets across steps)");
-    static_assert(GE::NC0 >= 2, "the first recurrent chunk must be requested after the previous step's epilogue");
+    static_assert(GE::NC0 >= 3, "the first recurrent chunk (and the poll for it, a chunk earlier) must be requested after the previous step's epilogue");
     constexpr int ROWS = GE::ROWS, NC0 = GE::NC0, NT = GE::NT, NST = GE::NST, STAGE = GE::STAGE;
     float *const ring = smem;               // [NST][ROWS][64], 16-byte chunks XOR-swizzled by the row
     float *const Sg = smem + NST * STAGE;   // [ROWS][4 gates][16 units] pre-activations of the step
-    int *const sm_flag = reinterpret_cast<int *>(smem + (NST + 1) * STAGE); // broadcast of wave 0's poll result
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS;
     const int Kin = l == 0 ? a.E : R;
@@ -137,7 +145,6 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
 
     // staging map of a K chunk: thread -> float4 (row = tid / 16 + 16 j, 16-byte chunk kq = tid % 16)
     const int srow = tid >> 4, skq = tid & 15;
-    const bool h0_live = a.h0_top && l == a.L - 1;
 
     // active steps of this row block form one contiguous range [t_lo, t_hi): arch1 rows start late and stay
     // (misc/RNNUtils.lua:136-145), arch2 rows all stop at tmax (Encoder_lstm.lua:185-189)
@@ -150,82 +157,131 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         t_hi = t;
     }
 
+    // per-thread / per-workgroup invariants of the activation loads (all 32-bit: every buffer is < 2 GB)
+    const unsigned step_bytes0 = (unsigned)B * Kin * 4, step_bytes1 = (unsigned)B * R * 4;
+    const unsigned rstride0 = 16u * Kin * 4, rstride1 = 16u * R * 4;
+    const unsigned toff0 = ((unsigned)(r0 + srow) * Kin + 4 * skq) * 4, toff1 = ((unsigned)(r0 + srow) * R + 4 * skq) * 4;
+    const int jmax = r0 + srow < B ? (B - r0 - srow + 15) / 16 : 0; // rows r0 + srow + 16 j < B  <=>  j < jmax
+
     pf_u32x4 stg[2][MT];
-    // request chunk q of step t into staging set SET; where the bytes are another workgroup's, wait for its counter
-    auto prefetch = [&](int t, auto q_tag, auto set_tag) -> bool {
+    unsigned pend = 0; // value of the counter the next flagged chunk depends on, requested a chunk ahead of its use
+    // ask for the counter that chunk q of step t waits for (always a load -- of counter 0 when nothing is awaited --
+    // so that no load sits under a runtime branch)
+    auto poll_request = [&](int t, auto q_tag, bool en) {
+        constexpr int q = decltype(q_tag)::value;
+        static_assert(q == 0 || q == NC0, "only the first chunk of a segment waits");
+        const bool flagged = en && (q == 0 ? l > 0 : t > 0);
+        const size_t idx = !flagged ? 0 : (q == 0 ? ((size_t)(l - 1) * a.RB + rb) * TS + t : ((size_t)l * a.RB + rb) * TS + (t - 1));
+        pend = __hip_atomic_load(a.cnt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // request chunk q of step t into staging set SET; where the bytes are another workgroup's, wait for its counter.
+    // The loads are issued on EVERY path (en = false: out-of-range offsets, which return zeros without touching
+    // memory): a load under a runtime branch makes hipcc wait vmcnt(0) at the join, i.e. for the chunk just requested
+    // instead of the one requested an iteration ago (cdna_hip_programming.md section 5, trap (c)).
+    unsigned pf_o0 = PF_OOB; // offset of the thread's first piece of the chunk being requested
+    auto prefetch_begin = [&](int t, auto q_tag, bool en) {
+        constexpr int q = decltype(q_tag)::value;
+        constexpr bool s1 = q >= NC0;
+        // (step 0 multiplies the recurrent chunks too: slice 0 of Hs holds h_{-1} = 0, or the carried h0 of
+        // NVQA_QUIRK_H0 -- one step of 26 with 50 % more MFMAs is cheaper than a second copy of the unrolled chunk
+        // loop, which would push the per-step code of the two layers past the 64 KB instruction cache)
+        // hand-off check, per wave (MI355X_MICROARCH.md "Valid forms" row 1: a wave loads handed-off bytes after ITS poll of
+        // the producers' counter matched): the counter was requested one chunk earlier (poll_request), so this is
+        // normally a register compare; a late producer costs a bounded spin.  A timeout sets err and goes on -- the
+        // launch always drains, the host reports the step as failed.
+        if constexpr (q == 0 || q == NC0) {
+            const bool flagged = q == 0 ? l > 0 : t > 0;
+            if (flagged && en && !(a.dbg & 1) && pend < (unsigned)a.NU) {
+                unsigned *need = q == 0 ? a.cnt + ((size_t)(l - 1) * a.RB + rb) * TS + t : a.cnt + ((size_t)l * a.RB + rb) * TS + (t - 1);
+                (void)pf_wait_ge(need, (unsigned)a.NU, a.err, (q == 0 ? 0x100u : 0x200u) + l);
+            }
+        }
+        if (a.dbg & 8) en = false;
+        // OR-ed into every offset; readfirstlane keeps it a scalar the optimiser does not look through, or it clones
+        // the loads into an `en` and a `!en` branch and the waits at the join cover both
+        const unsigned enm = __builtin_amdgcn_readfirstlane(en ? 0u : PF_OOB);
+        constexpr int c = s1 ? q - NC0 : q;
+        // byte offset of this thread's first float4 of the chunk: step base (scalar) + thread part (precomputed) + 256 c;
+        // row j of the thread's MT rows is 16 rows further: + j * rstride.  Out-of-range pieces get PF_OOB (| or + keeps
+        // them beyond every buffer), 2 vector instructions per load in all.
+        const unsigned sbase = (unsigned)t * (s1 ? step_bytes1 : step_bytes0) + 256u * c;
+        pf_o0 = ((64 * c + 4 * skq < (s1 ? R : Kin)) ? (s1 ? toff1 : toff0) + sbase : PF_OOB) | enm;
+    };
+    // loads j0 .. j1-1 of the chunk prepared by prefetch_begin (one or two per MFMA pair: a burst of MT loads between
+    // two groups idles the matrix pipe for the time it takes to issue them)
+    auto prefetch_piece = [&](auto q_tag, auto set_tag, auto j0_tag, auto j1_tag) {
         constexpr int q = decltype(q_tag)::value, SET = decltype(set_tag)::value;
         constexpr bool s1 = q >= NC0;
-        if (s1 && !(t > 0 || h0_live)) return true; // h_{-1} = 0: no recurrent product at step 0
-        unsigned *need = nullptr;
-        unsigned code = 0;
-        if (q == 0 && l > 0) { need = a.cnt + ((size_t)(l - 1) * a.RB + rb) * TS + t; code = 0x100u + l; }
-        if (q == NC0 && t > 0) { need = a.cnt + ((size_t)l * a.RB + rb) * TS + (t - 1); code = 0x200u + l; }
-        if (need) {
-            if (wave == 0) {
-                const bool ok = pf_wait_ge(need, (unsigned)a.NU, a.err, code);
-                if (lane == 0) *sm_flag = ok ? 1 : 0;
-            }
-            __syncthreads();
-            const int ok = *sm_flag;
-            __syncthreads(); // the flag word may be rewritten by the next wait
-            if (!ok) return false;
-        }
-        constexpr int c = s1 ? q - NC0 : q;
-        const int kw = s1 ? R : Kin;
-        const size_t base = (size_t)t * B * kw; // Hs slice t = h_{t-1}; input slice t
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int row = r0 + srow + 16 * j, k = 64 * c + 4 * skq;
-            const unsigned off = (row < B && k < kw) ? (unsigned)((base + (size_t)row * kw + k) * 4) : PF_OOB;
+        for (int j = decltype(j0_tag)::value; j < decltype(j1_tag)::value && j < MT; ++j) {
+            const unsigned off = j < jmax ? pf_o0 + (unsigned)j * (s1 ? rstride1 : rstride0) : PF_OOB;
             stg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_h : r_in, off, 0, 16 /* sc1 */);
         }
-        return true;
     };
-    auto commit = [&](auto set_tag, int stage) {
+    auto prefetch = [&](int t, auto q_tag, auto set_tag, bool en) {
+        prefetch_begin(t, q_tag, en);
+        prefetch_piece(q_tag, set_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
+    };
+    auto commit_piece = [&](auto set_tag, int stage, auto j0_tag, auto j1_tag) {
         constexpr int SET = decltype(set_tag)::value;
         float *dst = ring + stage * STAGE;
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
+        for (int j = decltype(j0_tag)::value; j < decltype(j1_tag)::value && j < MT; ++j) {
             const int row = srow + 16 * j;
             *reinterpret_cast<pf_u32x4 *>(&dst[row * 64 + 4 * (skq ^ (row & 15))]) = stg[SET][j];
         }
     };
+    auto commit = [&](auto set_tag, int stage) {
+        commit_piece(set_tag, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
+    };
 
     pf_f32x4 acc[MT];
-    // MFMAs of chunk q (compile time: it selects the resident B fragments) from ring stage `stage`
-    auto compute = [&](auto q_tag, int stage) {
-        constexpr int q = decltype(q_tag)::value;
+    pf_f32x4 af[MT]; // A fragments of the group about to be multiplied (carried across chunks and steps)
+    // MFMAs of group g of chunk q (compile time: they select the resident B fragments).  The A fragments of a
+    // row-tile pair are replaced right after the pair's MFMAs -- by the next group of the chunk, or (last group) by
+    // the first group of the NEXT chunk from ring stage `nxt` -- so a full group of other pairs' MFMAs hides the LDS
+    // latency with one fragment set; the two row tiles of a pair alternate so that an accumulator is reused every
+    // second MFMA (40-cycle dependent latency, 32-cycle issue).
+    auto mfma_group = [&](auto q_tag, auto g_tag, const float *cur, const float *nxt, auto &&hook) {
+        constexpr bool live = true;
+        constexpr int q = decltype(q_tag)::value, g = decltype(g_tag)::value;
         constexpr bool s1 = q >= NC0;
         constexpr int c = s1 ? q - NC0 : q;
-        constexpr int GB = s1 ? G0 + 4 * c : 4 * c;                          // first B-fragment group of the chunk
-        constexpr int NG = s1 ? 4 : (4 * c + 4 <= G0 ? 4 : G0 - 4 * c);      // groups with data in the chunk
-        const float *src = ring + stage * STAGE;
-        // A fragments of a row-tile pair are re-read for the next group right after the pair's MFMAs of this group
-        // (a full group of other pairs' MFMAs hides the LDS latency) -- one fragment set instead of two; the two row
-        // tiles of a pair alternate so that an accumulator is reused every second MFMA (40-cycle dependent latency)
-        pf_f32x4 af[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const pf_f32x4 *>(&src[(m * 16 + li) * 64 + 4 * (lh ^ li)]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int mp = 0; mp < MT; mp += 2) {
+        constexpr int GB = s1 ? G0 + 4 * c : 4 * c;                     // first B-fragment group of the chunk
+        constexpr int NG = s1 ? 4 : (4 * c + 4 <= G0 ? 4 : G0 - 4 * c); // groups with data in the chunk
+        if constexpr (g < NG) {
+            auto pair = [&](auto mp_tag) {
+                constexpr int mp = decltype(mp_tag)::value;
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
 #pragma unroll
                     for (int m = mp; m < mp + 2 && m < MT; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][w], bw[4 * (GB + g) + w], acc[m], 0, 0, 0);
-                if (g + 1 < NG) {
+                const float *src = g + 1 < NG ? cur : nxt;
+                constexpr int gn = g + 1 < NG ? g + 1 : 0;
 #pragma unroll
-                    for (int m = mp; m < mp + 2 && m < MT; ++m)
-                        af[m] = *reinterpret_cast<const pf_f32x4 *>(&src[(m * 16 + li) * 64 + 4 * ((4 * (g + 1) + lh) ^ li)]);
-                }
-            }
+                for (int m = mp; m < mp + 2 && m < MT; ++m)
+                    af[m] = *reinterpret_cast<const pf_f32x4 *>(&src[(m * 16 + li) * 64 + 4 * ((4 * gn + lh) ^ li)]);
+                hook(mp_tag); // a piece of the next chunks' housekeeping, under this pair's MFMAs
+                // keep the refill (and the piece) HERE: left alone, hipcc sinks these reads to just above their first use
+                // (shorter live range) and every pair then opens with an exposed LDS round trip -- 15 % of the step
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            [&]<int... P>(std::integer_sequence<int, P...>) { (pair(std::integral_constant<int, 2 * P>{}), ...); }(std::make_integer_sequence<int, (MT + 1) / 2>{});
         }
+    };
+    auto chunk_groups = [](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        constexpr bool s1 = q >= NC0;
+        constexpr int c = s1 ? q - NC0 : q;
+        return std::integral_constant<int, (s1 ? 4 : (4 * c + 4 <= G0 ? 4 : G0 - 4 * c))>{};
     };
 
     // fused cell for step t (active = false: the whole row block has not started / has stopped: zeros), then publish
-    auto epilogue = [&](int t, bool act) {
+    auto publish = [&](int t) {
+        if (tid == 0) __hip_atomic_fetch_add(a.cnt + ((size_t)l * a.RB + rb) * TS + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto epilogue = [&](int t, bool act, bool defer) {
         if (act) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -245,7 +301,8 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         for (int e = 0; e < NE; ++e) {
             const int row = erow + 64 * e, grow = r0 + row;
             if (row >= ROWS || grow >= B) continue;
-            const bool on = act && grow < nr;
+            const bool on = act && grow < nr && !(a.dbg & 2);
+            if ((a.dbg & 2) && e >= 0) continue;
             pf_f32x4 gi = {0.f, 0.f, 0.f, 0.f}, gf = gi, go = gi, gg = gi, cn = gi, hn = gi, un = gi;
             if (on) {
                 const pf_f32x4 p0 = *reinterpret_cast<const pf_f32x4 *>(&Sg[(row * 4 + 0) * 16 + 4 * eq]);
@@ -253,15 +310,30 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
                 const pf_f32x4 p2 = *reinterpret_cast<const pf_f32x4 *>(&Sg[(row * 4 + 2) * 16 + 4 * eq]);
                 const pf_f32x4 p3 = *reinterpret_cast<const pf_f32x4 *>(&Sg[(row * 4 + 3) * 16 + 4 * eq]);
                 const uint64_t didx = ((((uint64_t)l) * B + a.sort_idx[grow]) * TS + t) * R + u0 + 4 * eq;
+                if (a.dbg & 16) { // libdevice expf / tanhf (A/B against the hardware forms)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    gi[j] = sigmoidf_(p0[j] + bias[0][j]);
-                    gf[j] = sigmoidf_(p1[j] + bias[1][j]);
-                    go[j] = sigmoidf_(p2[j] + bias[2][j]);
-                    gg[j] = tanhf_(p3[j] + bias[3][j]);
-                    cn[j] = gf[j] * cst[e][j] + gi[j] * gg[j];
-                    hn[j] = go[j] * tanhf_(cn[j]);
-                    if (has_next) un[j] = a.dr.scale(NVQA_SITE_LSTM, didx + j) * hn[j];
+                    for (int j = 0; j < 4; ++j) {
+                        gi[j] = sigmoidf_(p0[j] + bias[0][j]);
+                        gf[j] = sigmoidf_(p1[j] + bias[1][j]);
+                        go[j] = sigmoidf_(p2[j] + bias[2][j]);
+                        gg[j] = tanhf_(p3[j] + bias[3][j]);
+                        cn[j] = gf[j] * cst[e][j] + gi[j] * gg[j];
+                        hn[j] = go[j] * tanhf_(cn[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gi[j] = pf_sigmoid(p0[j] + bias[0][j]);
+                        gf[j] = pf_sigmoid(p1[j] + bias[1][j]);
+                        go[j] = pf_sigmoid(p2[j] + bias[2][j]);
+                        gg[j] = pf_tanh(p3[j] + bias[3][j]);
+                        cn[j] = gf[j] * cst[e][j] + gi[j] * gg[j];
+                        hn[j] = go[j] * pf_tanh(cn[j]);
+                    }
+                }
+                if (has_next) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) un[j] = a.dr.scale(NVQA_SITE_LSTM, didx + j) * hn[j];
                 }
             }
 #pragma unroll
@@ -279,56 +351,85 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, un), r_un,
                                                        (unsigned)((srow_g * R + u0 + 4 * eq) * 4), 0, 16);
         }
+        if (defer) return; // drained and signalled from the next step's first chunk, under its MFMAs (publish_deferred)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.cnt + ((size_t)l * a.RB + rb) * TS + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish(t);
     };
 
     // ---- steps before the row block starts ----------------------------------------------------------------------
-    for (int t = 0; t < t_lo; ++t) epilogue(t, false);
+    for (int t = 0; t < t_lo; ++t) epilogue(t, false, false);
 
     if (t_lo < t_hi) {
         unsigned n = 0; // running chunk counter: ring stage = n % NST
-        bool ok = true;
         // pipeline prologue: chunks 0 and 1 of the first active step
-        ok = prefetch(t_lo, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        if (ok) {
-            commit(std::integral_constant<int, 0>{}, 0);
-            ok = prefetch(t_lo, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-        }
-        for (int t = t_lo; t < t_hi && ok; ++t) {
+        poll_request(t_lo, std::integral_constant<int, 0>{}, true);
+        prefetch(t_lo, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, true);
+        commit(std::integral_constant<int, 0>{}, 0);
+        prefetch(t_lo, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, true);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const pf_f32x4 *>(&ring[(m * 16 + li) * 64 + 4 * (lh ^ li)]);
+        int pub = -1; // step whose h / Dropout(h) stores are issued but not yet drained and signalled
+        for (int t = t_lo; t < t_hi; ++t) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-            const bool s1_now = t > 0 || h0_live, more = t + 1 < t_hi;
+            const bool more = t + 1 < t_hi;
             auto iter = [&](auto q_tag) {
                 constexpr int q = decltype(q_tag)::value;
-                if (!ok) return;
-                // A: request chunk q+2 (this step or the next) into the staging set chunk q has just left
-                if constexpr (q + 2 < NT) {
-                    ok = prefetch(t, std::integral_constant<int, q + 2>{}, std::integral_constant<int, q & 1>{});
-                } else {
-                    if (more) ok = prefetch(t + 1, std::integral_constant<int, q + 2 - NT>{}, std::integral_constant<int, q & 1>{});
+                constexpr int NG = decltype(chunk_groups(q_tag))::value;
+                const float *cur = ring + (n % NST) * STAGE, *nxt = ring + ((n + 1) % NST) * STAGE;
+                // The housekeeping of the NEXT chunks sits between the MFMA groups of this one, so that the matrix
+                // pipe never waits for it (one wave per SIMD: nobody else would fill the gap):
+                //   group 0 | request chunk q+2 | group 1 | chunk q+1 -> LDS | group 2 | barrier | group 3 (+ first
+                //   fragments of chunk q+1).  Chunks with fewer groups keep the order of the remaining pieces.
+                // chunk q+2: flag check + offsets now, its loads two per MFMA pair under group 0
+                if constexpr (q + 2 < NT) prefetch_begin(t, std::integral_constant<int, q + 2>{}, true);
+                else prefetch_begin(more ? t + 1 : t, std::integral_constant<int, q + 2 - NT>{}, more);
+                constexpr int QN = q + 2 < NT ? q + 2 : q + 2 - NT; // index of that chunk inside its step
+                auto none = [](auto) {};
+                auto loads = [&](auto mp_tag) {
+                    constexpr int mp = decltype(mp_tag)::value;
+                    prefetch_piece(std::integral_constant<int, QN>{}, std::integral_constant<int, q & 1>{},
+                                   std::integral_constant<int, mp>{}, std::integral_constant<int, mp + 2>{});
+                };
+                auto writes = [&](auto mp_tag) { // chunk q+1 -> LDS (a chunk that does not exist arrives as zeros, never multiplied)
+                    constexpr int mp = decltype(mp_tag)::value;
+                    commit_piece(std::integral_constant<int, (q + 1) & 1>{}, (int)((n + 1) % NST), std::integral_constant<int, mp>{},
+                                 std::integral_constant<int, mp + 2>{});
+                };
+                if constexpr (NG > 1) mfma_group(q_tag, std::integral_constant<int, 0>{}, cur, nxt, loads);
+                else prefetch_piece(std::integral_constant<int, QN>{}, std::integral_constant<int, q & 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
+                // counter of the flagged chunk that is requested NEXT iteration (chunk q+3), one chunk ahead of its use
+                if constexpr (q + 3 == NC0) poll_request(t, std::integral_constant<int, NC0>{}, true);
+                if constexpr (q + 3 == NT) poll_request(more ? t + 1 : t, std::integral_constant<int, 0>{}, more);
+                if constexpr (NG > 2) mfma_group(q_tag, std::integral_constant<int, 1>{}, cur, nxt, writes);
+                else commit(std::integral_constant<int, (q + 1) & 1>{}, (int)((n + 1) % NST));
+                if constexpr (NG > 3) mfma_group(q_tag, std::integral_constant<int, 2>{}, cur, nxt, none);
+                if constexpr (q == 0) {
+                    // the previous step's write-through stores are older than the MT loads of the prefetch above: drained
+                    // here, signalled behind this chunk's barrier (publish R1: every storing wave drains, barrier, one lane)
+                    if (pub >= 0) {
+                        if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    }
                 }
-                if (!ok) return;
-                // B: chunk q+1 -> LDS
-                bool have_next;
-                if constexpr (q + 1 < NT) have_next = (q + 1 < NC0) || s1_now;
-                else have_next = more;
-                if (have_next) commit(std::integral_constant<int, (q + 1) & 1>{}, (int)((n + 1) % NST));
                 __syncthreads();
-                // C: multiply chunk q
-                if ((q < NC0) || s1_now) compute(q_tag, (int)(n % NST));
+                if constexpr (q == 0) {
+                    if (pub >= 0) { publish(pub); pub = -1; }
+                }
+                // last group of the chunk: its fragment refills come from chunk q+1, published by the barrier above
+                mfma_group(q_tag, std::integral_constant<int, NG - 1>{}, cur, nxt, none);
                 ++n;
             };
             // the chunks of a step, unrolled: each one names its own resident B fragments
             [&]<int... Q>(std::integer_sequence<int, Q...>) { (iter(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NT>{});
-            if (!ok) break;
-            epilogue(t, true);
+            epilogue(t, true, more);
+            if (more) pub = t;
         }
-        if (!ok) return; // a wait timed out: err is set, every wave of the workgroup leaves together
     }
     // ---- steps after the row block has stopped (arch2: t >= tmax) ---------------------------------------------------
-    for (int t = t_hi; t < TS; ++t) epilogue(t, false);
+    for (int t = t_hi; t < TS; ++t) epilogue(t, false, false);
 }
 
 // G0A: K groups of layer 0's input (ceil(E / 16)); GR = R / 16.  Workgroup id -> (layer, row block, unit tile): the

@@ -310,9 +310,9 @@ static int create_impl(nvqa_ctx *c)
         c->use_ring = env && env[0] == '1' && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
         if (c->use_ring) NVQA_TRY(dalloc(&c->WT, (size_t)L * 2 * 4 * R * R));
     }
-    {   // persistent forward LSTM (lstm_persist.h): NVQA_PERSIST=1 opts in
+    {   // persistent forward LSTM (lstm_persist.h) where the shape is eligible; NVQA_PERSIST=0: one launch per wavefront level
         const char *ep = getenv("NVQA_PERSIST");
-        c->persist_on = ep && ep[0] == '1';
+        c->persist_on = !(ep && ep[0] == '0');
         hipDeviceProp_t prop;
         NVQA_HIP(hipGetDeviceProperties(&prop, c->device));
         c->num_cus = prop.multiProcessorCount;
@@ -537,10 +537,16 @@ template <int G0A, int GR, int MT>
 static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 {
     const size_t lds = std::max(PersistGeom<G0A, GR, MT>::LDS_BYTES, PersistGeom<GR, GR, MT>::LDS_BYTES);
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
+    static int resident = -1; // per instantiation: workgroups of this kernel one CU can hold
+    if (resident < 0) {
         NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<G0A, GR, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        int nb = 0;
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<G0A, GR, MT>, NVQA_PF_THREADS, lds));
+        resident = nb;
+    }
+    if (resident < 1 || grid > c->num_cus) { // the workgroups wait for each other: all of them must be resident at once
+        set_error("persistent LSTM kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
+        return -1;
     }
     hipLaunchKernelGGL((k_lstm_fwd_persist<G0A, GR, MT>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
@@ -574,6 +580,7 @@ static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     a.RB = (B + 16 * MT - 1) / (16 * MT); a.NU = R / 16;
     a.h0_top = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) ? 1 : 0;
     a.dr = dr;
+    { static const int dbg = [] { const char *e = getenv("NVQA_PF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
     const int grid = L * a.RB * a.NU;
     double flops = 0;
