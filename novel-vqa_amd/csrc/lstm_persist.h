@@ -47,6 +47,7 @@ struct PersistFwdArgs {
     unsigned *cnt; // [L][RB][TS] arrival counters, zeroed before the launch
     unsigned *err; // != 0: a spin timed out (the launch still drains)
     int B, R, E, L, TS, RB, NU;
+    unsigned spin_limit; // polls before a wave gives up (NVQA_PF_SPIN_LIMIT unless NVQA_PF_SPIN overrides it)
     int dbg;       // measurement only (NVQA_PF_DBG): 1 no flag waits, 2 no cell math / stores, 8 activation loads without
                    // memory traffic, 16 libdevice instead of hardware exp / rcp in the cell
     int h0_top;    // arch2 NVQA_QUIRK_H0: the top layer's h_{-1} (slice 0 of Hs) is live at step 0
@@ -68,14 +69,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pf_rsrc(const void *p, size_t 
 #define PF_OOB 0x7ffffffcu // beyond every buffer: an out-of-range raw buffer load returns zeros, a store is dropped
 
 // bounded wait for *word >= want (sc1 loads; called by one wave); false = timed out
-__device__ __forceinline__ bool pf_wait_ge(unsigned *word, unsigned want, unsigned *err, unsigned code)
+__device__ __forceinline__ bool pf_wait_ge(unsigned *word, unsigned want, unsigned *err, unsigned code, unsigned limit = NVQA_PF_SPIN_LIMIT)
 {
     unsigned spins = 0;
     for (;;) {
         const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= want) return true;
-        if (++spins > NVQA_PF_SPIN_LIMIT) {
-            __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > limit) {
+            // first give-up wins the record: {code, word index (set by the caller's code), value seen, workgroup}
+            unsigned expect = 0;
+            if (__hip_atomic_compare_exchange_strong(err, &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(err + 1, (unsigned)(word - (err - 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(err + 2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(err + 3, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return false;
         }
         if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
@@ -105,7 +112,11 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS;
     const int Kin = l == 0 ? a.E : R;
-    const int r0 = rb * ROWS;
+    // Rows are dealt to the row blocks round-robin: local row i of block rb is sorted batch row rb + RB i.  (The host
+    // launches this kernel only for batches whose rows are all active whenever any is -- equal-length arch1 batches and
+    // arch2 -- so every row tile always has work; a ragged instance that skipped row tiles per step needed a branch per
+    // MFMA pair, 8 % on the full-length case, and was dropped.  Ragged batches take the per-level kernels.)
+    const int RBn = a.RB;
     const int u0 = ut * 16;
 
     // ---- weights of gate `wave`, units u0 .. u0+15, all of K: B fragments, resident for the whole launch ----------
@@ -151,17 +162,18 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     int t_lo = 0, t_hi = 0;
     {
         int t = 0;
-        while (t < TS && r0 >= a.nrows[t]) ++t;
+        while (t < TS && rb >= a.nrows[t]) ++t;
         t_lo = t;
-        while (t < TS && r0 < a.nrows[t]) ++t;
+        while (t < TS && rb < a.nrows[t]) ++t;
         t_hi = t;
     }
 
     // per-thread / per-workgroup invariants of the activation loads (all 32-bit: every buffer is < 2 GB)
     const unsigned step_bytes0 = (unsigned)B * Kin * 4, step_bytes1 = (unsigned)B * R * 4;
-    const unsigned rstride0 = 16u * Kin * 4, rstride1 = 16u * R * 4;
-    const unsigned toff0 = ((unsigned)(r0 + srow) * Kin + 4 * skq) * 4, toff1 = ((unsigned)(r0 + srow) * R + 4 * skq) * 4;
-    const int jmax = r0 + srow < B ? (B - r0 - srow + 15) / 16 : 0; // rows r0 + srow + 16 j < B  <=>  j < jmax
+    const unsigned rstride0 = 16u * RBn * Kin * 4, rstride1 = 16u * RBn * R * 4;
+    const unsigned grow0 = (unsigned)(rb + RBn * srow); // sorted batch row of this thread's first staged row
+    const unsigned toff0 = (grow0 * Kin + 4 * skq) * 4, toff1 = (grow0 * R + 4 * skq) * 4;
+    const int jmax = (int)grow0 < B ? (B - (int)grow0 + 16 * RBn - 1) / (16 * RBn) : 0; // rows grow0 + 16 RB j < B  <=>  j < jmax
 
     pf_u32x4 stg[2][MT];
     unsigned pend = 0; // value of the counter the next flagged chunk depends on, requested a chunk ahead of its use
@@ -193,7 +205,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
             const bool flagged = q == 0 ? l > 0 : t > 0;
             if (flagged && en && !(a.dbg & 1) && pend < (unsigned)a.NU) {
                 unsigned *need = q == 0 ? a.cnt + ((size_t)(l - 1) * a.RB + rb) * TS + t : a.cnt + ((size_t)l * a.RB + rb) * TS + (t - 1);
-                (void)pf_wait_ge(need, (unsigned)a.NU, a.err, (q == 0 ? 0x100u : 0x200u) + l);
+                (void)pf_wait_ge(need, (unsigned)a.NU, a.err, (q == 0 ? 0x100u : 0x200u) + l, a.spin_limit);
             }
         }
         if (a.dbg & 8) en = false;
@@ -278,8 +290,10 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     };
 
     // fused cell for step t (active = false: the whole row block has not started / has stopped: zeros), then publish
+    const unsigned cbase = (unsigned)((l * a.RB + rb) * TS); // this workgroup's (layer, row block) counters
     auto publish = [&](int t) {
-        if (tid == 0) __hip_atomic_fetch_add(a.cnt + ((size_t)l * a.RB + rb) * TS + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned idx = cbase + (unsigned)__builtin_amdgcn_readfirstlane(t); // scalar, 32-bit: see `pub` below
+        if (tid == 0) __hip_atomic_fetch_add(a.cnt + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto epilogue = [&](int t, bool act, bool defer) {
         if (act) {
@@ -299,7 +313,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int row = erow + 64 * e, grow = r0 + row;
+            const int row = erow + 64 * e, grow = rb + RBn * row;
             if (row >= ROWS || grow >= B) continue;
             const bool on = act && grow < nr && !(a.dbg & 2);
             if ((a.dbg & 2) && e >= 0) continue;
@@ -370,7 +384,10 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const pf_f32x4 *>(&ring[(m * 16 + li) * 64 + 4 * (lh ^ li)]);
-        int pub = -1; // step whose h / Dropout(h) stores are issued but not yet drained and signalled
+        // step whose h / Dropout(h) stores are issued but not yet drained and signalled.  (publish() takes it through
+        // readfirstlane into 32-bit index arithmetic: as a sign-extended 64-bit vector index, at the 512-register
+        // limit this kernel runs at, hipcc 7.2 lost the high half in one build and the add went astray.)
+        int pub = -1;
         for (int t = t_lo; t < t_hi; ++t) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = pf_f32x4{0.f, 0.f, 0.f, 0.f};

@@ -318,8 +318,8 @@ static int create_impl(nvqa_ctx *c)
         c->num_cus = prop.multiProcessorCount;
         c->pf_cnt_words = ((size_t)L * ((B + 63) / 64) * TS + 4 + 3) / 4 * 4; // counters for the finest row blocking + err word, 16-byte multiple
         NVQA_TRY(dalloc(&c->pf_cnt, c->pf_cnt_words));
-        NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, sizeof(unsigned), hipHostMallocDefault));
-        *c->h_pf_err = 0;
+        NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 4 * sizeof(unsigned), hipHostMallocDefault));
+        memset(c->h_pf_err, 0, 16);
     }
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
@@ -363,7 +363,10 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
 static int check_persist(nvqa_ctx *c)
 {
     if (c->h_pf_err && *c->h_pf_err) {
-        set_error("persistent LSTM kernel: a workgroup timed out waiting for its neighbours (code 0x%x); results of that step are invalid", *c->h_pf_err);
+        // word index relative to the err word: counters end 4 words before it
+        const long widx = (long)(int)c->h_pf_err[1] + (long)c->pf_cnt_words - 4;
+        set_error("persistent LSTM kernel: workgroup %u timed out waiting (code 0x%x, counter word %ld = (layer,rowblock) %ld step %ld, value seen %u); "
+                  "results of that step are invalid", c->h_pf_err[3], c->h_pf_err[0], widx, widx / c->TS, widx % c->TS, c->h_pf_err[2]);
         *c->h_pf_err = 0;
         c->persist_on = false; // later steps take the per-level path
         return -3;
@@ -557,6 +560,9 @@ static int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT)
 {
     const nvqa_dims &d = c->d;
     if (!c->persist_on || c->bf16 || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
+    // every row must be active whenever any row is: arch2 always (all rows run to tmax), arch1 when the host knows that
+    // all questions of the batch have one length; ragged arch1 batches take the per-level kernels
+    if (d.arch == NVQA_ARCH1 && !c->batch_uniform) return 0;
     const int NU = d.R / 16;
     for (int MT : {4, 8}) { // the smallest row block that still gives every workgroup its own CU
         const int RB = (d.B + 16 * MT - 1) / (16 * MT);
@@ -581,6 +587,7 @@ static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     a.h0_top = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) ? 1 : 0;
     a.dr = dr;
     { static const int dbg = [] { const char *e = getenv("NVQA_PF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+    { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
     a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
     const int grid = L * a.RB * a.NU;
     double flops = 0;
@@ -594,7 +601,7 @@ static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
         if (MT == 4) NVQA_TRY((launch_persist_fwd<32, 32, 4>(c, a, grid)));
         else NVQA_TRY((launch_persist_fwd<32, 32, 8>(c, a, grid)));
     }
-    NVQA_HIP(hipMemcpyAsync(c->h_pf_err, a.err, 4, hipMemcpyDeviceToHost, c->s));
+    NVQA_HIP(hipMemcpyAsync(c->h_pf_err, a.err, 16, hipMemcpyDeviceToHost, c->s));
     return 0;
 }
 
@@ -1059,6 +1066,8 @@ static int upload_batch(nvqa_ctx *c, int n, const int32_t *tokens, const int32_t
             lb[b] = labels[sb];
         }
     }
+    c->batch_uniform = true;
+    for (size_t b = 1; b < B; ++b) c->batch_uniform = c->batch_uniform && ln[b] == ln[0];
     NVQA_HIP(hipStreamSynchronize(c->s));
     NVQA_HIP(hipMemcpy(c->tok, tk.data(), B * T * 4, hipMemcpyHostToDevice));
     NVQA_HIP(hipMemcpy(c->len, ln.data(), B * 4, hipMemcpyHostToDevice));
@@ -1246,6 +1255,9 @@ extern "C" int nvqa_dataset_load(nvqa_ctx *c, int64_t n_q, const int32_t *questi
     }
     ds.n_q = n_q;
     ds.n_img = n_img;
+    ds.uniform_len = true; // all questions of one length: every batch drawn from the dataset is full-length
+    if (lengths)
+        for (int64_t q = 1; q < n_q; ++q) ds.uniform_len = ds.uniform_len && lengths[q] == lengths[0];
     if (l2_normalize > 1 && (l2_normalize >= d.I || l2_normalize % 4)) { set_error("l2_normalize split %d must be a multiple of 4 below I=%d", l2_normalize, d.I); return -1; }
     if (l2_normalize > 1) {
         hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I, 0, l2_normalize);
@@ -1268,6 +1280,7 @@ extern "C" int nvqa_step_indices(nvqa_ctx *c, const int64_t *qinds, const nvqa_d
     for (int b = 0; b < d.B; ++b)
         if (qinds[b] < 0 || qinds[b] >= c->ds.n_q) { set_error("qinds[%d]=%lld outside 0..%lld", b, (long long)qinds[b], (long long)c->ds.n_q - 1); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
+    c->batch_uniform = c->ds.uniform_len;
     NVQA_HIP(hipMemcpyAsync(c->qinds, qinds, (size_t)d.B * 8, hipMemcpyHostToDevice, c->s));
     {
         ProfScope ps(c, PF_GATHER, 0, 2.0 * d.B * d.I * 4);

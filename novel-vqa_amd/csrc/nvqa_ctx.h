@@ -62,6 +62,7 @@ struct Dataset {
     int64_t n_q = 0, n_img = 0;
     int32_t *Q = nullptr, *QL = nullptr, *IP = nullptr, *ANS = nullptr;
     float *F = nullptr;
+    bool uniform_len = false; // every question has the same length (host check at load)
 };
 
 } // namespace nvqa
@@ -106,6 +107,7 @@ struct nvqa_ctx {
     float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
     bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate
     bool fold_i2h = true;         // layer-0 input projection as a first K segment of the level kernel; NVQA_FOLD_I2H=0: separate time-batched GEMM
+    bool batch_uniform = false;   // current batch: all lengths equal (known on the host)
     bool persist_on = false;      // forward LSTM as one persistent weight-stationary launch (lstm_persist.h)
     int num_cus = 0;
     unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed before every launch)

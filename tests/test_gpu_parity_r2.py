@@ -225,27 +225,34 @@ def test_arch2_reference_quirks_over_three_iterations(pkg, orc, flags, L):
     ctx.close()
 
 
-PERSIST_CASES = {
-    "arch1_all26": (FULL1, True),
-    "arch1_ragged": (FULL1, False),
-    "arch2_L2": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=2, I=2048, C=4, A=1000), False),
-    "arch2_L1": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000), False),
-    "arch1_B200": (dict(FULL1, B=200), False),    # 13 row tiles: partial row block, fewer workgroups than CUs
+PERSIST_CASES = {   # (dims, batch A full-length?, batch B: uniform length or None = ragged [arch1: falls back to the level path])
+    "arch1_all26": (FULL1, True, 9),
+    "arch1_ragged_then_back": (FULL1, True, None),
+    "arch2_L2": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=2, I=2048, C=4, A=1000), False, None),
+    "arch2_L1": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000), False, None),
+    "arch1_B200": (dict(FULL1, B=200), True, 5),    # 13 row tiles: partial row block, fewer workgroups than CUs
 }
 
 
 @pytest.mark.parametrize("name", list(PERSIST_CASES))
 def test_persistent_forward_lstm(pkg, orc, name):
-    """NVQA_PERSIST=1: the forward unroll as ONE weight-stationary launch (csrc/lstm_persist.h) against the f64
-    oracle at the init-regime tolerances; two different batches in a row (counters re-zeroed, no stale state) and
-    the second one repeated (bit-reproducible)."""
-    kw, full = PERSIST_CASES[name]
+    """The forward unroll as ONE weight-stationary launch (csrc/lstm_persist.h; taken for arch2 and for arch1 batches of
+    one question length) against the f64 oracle at the init-regime tolerances; two different batches in a row (counters
+    re-zeroed, no stale state; a ragged arch1 batch in between goes through the per-level kernels on the same buffers)
+    and the second one repeated (bit-reproducible)."""
+    kw, full, lenB = PERSIST_CASES[name]
     d = orc.make_dims(**kw)
     params = orc.synth_params(d)
     bA = orc.synth_batch(d, seed=123, full_length=full, min_len=3)
     bB = orc.synth_batch(d, seed=77, full_length=False, min_len=1)
     if d.arch == 2:
         bB[0][:, 9:] = 0   # another tmax
+    elif lenB is not None:  # every question lenB tokens long: the row blocks start at step T - lenB
+        tok, lens, img, lab = bB
+        lens[:] = lenB
+        left = np.zeros_like(tok)
+        left[:, :lenB] = np.random.default_rng(5).integers(1, d.V + 1, (d.B, lenB))
+        bB = (orc.right_align(left, lens), lens, img, lab)
     ctx = _ctx(pkg, d, {"NVQA_PERSIST": "1"})
     ctx.set_params(params)
     _check_step(pkg, orc, d, ctx, params, bA, orc.Dropout(1, 0.5, 123, 7), TOL_GRAD, f"persist_{name}_A")
