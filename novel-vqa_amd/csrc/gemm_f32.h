@@ -257,17 +257,20 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     // tile index -> (segment, k range)
     const bool kskip = SEG == 0 && g.kseg_limits != nullptr && g.seg_rows % BK == 0 && kbeg % BK == 0;
     int nk1 = active && kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
-    // kseg: count only the K-tiles that hold active rows; kit_* walks them in order (load_tiles is
-    // called with kt = 0, 1, 2, ... exactly once each)
-    int kit_seg = 0, kit_next = 0, kit_end = 0;
-    if (kskip && nk1 > 0) {
-        nk1 = 0;
-        const int s_lo = kbeg / g.seg_rows, s_hi = (kend - 1) / g.seg_rows;
-        for (int sgm = s_lo; sgm <= s_hi; ++sgm) {
-            const int lo = max(sgm * g.seg_rows, kbeg), hi = min(sgm * g.seg_rows + g.kseg_limits[sgm], kend);
-            if (hi > lo) nk1 += (hi - lo + BK - 1) / BK;
+    // kseg: only the K-tiles that hold active rows are multiplied, and they are dealt to the K slices ROUND-ROBIN (tile
+    // i of the active list goes to slice i % slices): a ragged batch has its active rows in the late steps, so
+    // contiguous slices would leave the last slice as long as ever and the others idle.  kit_* walks the active list
+    // (load_tiles is called with kt = 0, 1, 2, ... exactly once each and advances `slices` tiles per call).
+    int kit_seg = -1, kit_next = 0, kit_end = 0;
+    const int kz = gridDim.z > 1 ? (int)gridDim.z : 1; // slices (single-problem launches only carry kseg)
+    if (kskip) {
+        int total = 0;
+        const int nseg = (g.K + g.seg_rows - 1) / g.seg_rows;
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const int lim = min(g.kseg_limits[sgm], g.K - sgm * g.seg_rows);
+            if (lim > 0) total += (lim + BK - 1) / BK;
         }
-        kit_seg = s_lo - 1; // the iterator advances into the first non-empty group on first use
+        nk1 = active && total > z ? (total - z + kz - 1) / kz : 0;
     }
     const int nk2 = SEG > 0 && active ? (g.K2 + BK - 1) / BK : 0;
     const int nk = nk1 + nk2;
@@ -361,15 +364,17 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         }
         const bool s2 = SEG > 0 && kt >= nk1;
         int k0 = s2 ? (kt - nk1) * BK : kbeg + kt * BK;
-        const int kend = s2 ? g.K2 : min(g.K, kbeg + g.kslice);
+        const int kend = s2 ? g.K2 : (kskip ? g.K : min(g.K, kbeg + g.kslice));
         if (kskip) {
-            while (kit_next >= kit_end) {
-                ++kit_seg;
-                kit_next = max(kit_seg * g.seg_rows, kbeg);
-                kit_end = min(kit_seg * g.seg_rows + g.kseg_limits[kit_seg], kend);
+            for (int adv = kt == 0 ? z + 1 : kz; adv > 0; --adv) { // to my next tile of the active list
+                while (kit_seg < 0 || kit_next >= kit_end) {
+                    ++kit_seg;
+                    kit_next = kit_seg * g.seg_rows;
+                    kit_end = min(kit_seg * g.seg_rows + g.kseg_limits[kit_seg], g.K);
+                }
+                k0 = kit_next;
+                kit_next += BK;
             }
-            k0 = kit_next;
-            kit_next += BK;
         }
         const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
         int tap0 = 0, cK0 = 0;
