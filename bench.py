@@ -96,6 +96,143 @@ def cpu_baseline(w, budget_s=12.0, max_steps=24):
                       f"OpenMP C restatement oracle/nvqa_oracle.c, {dt:.1f} s"}
 
 
+def mean_len(w, ragged):
+    """expected question length of a drawn batch (bench datasets: all T, or U{3..T})"""
+    return (3 + w["T"]) / 2.0 if ragged else float(w["T"])
+
+
+def flops_per_qa_actual(w, ragged):
+    """FLOPs per QA pair of the work actually done: the LSTM part scales with the question length (arch1: padding
+    steps are skipped; arch2 runs every row to the longest question of the batch, i.e. T + 2 steps here)."""
+    full, _ = flops_per_qa(w)
+    if not ragged or w["arch"] == 2:
+        return full
+    E, R, L = w["E"], w["R"], w["L"]
+    per_tok = sum(2 * 4 * R * ((E if l == 0 else R) + R) for l in range(L))
+    return full - 3 * per_tok * (w["T"] - mean_len(w, True))
+
+
+def bench_one(pkg, w, args, rank, local_rank, world, dist, steps, warmup, ragged=False, bf16=False, roofline=True,
+              host_batches=False):
+    """One configuration: warmup, `steps` timed steps between barriers, optional per-kernel pass.  host_batches: the
+    JdJ-shaped nvqa_step entry (host batch in, three synchronous copies per call) instead of nvqa_step_indices."""
+    import torch
+    dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
+    try:
+        # rank: own sample ids and own dropout masks per rank; the parameter seed is common to all ranks
+        tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123, rank=rank)
+    except pkg.binding.NvqaError as e:
+        print(f"bench.py rank {rank}/{world}: nvqa_create failed: {e}", file=sys.stderr, flush=True)
+        if dist:
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    tr.init_params()  # same on every rank (counter-based)
+    if bf16:
+        tr.ctx.set_precision(1)
+    q, lens, img_pos, ans, feats = synth_dataset(w, 123, ragged)
+    tr.load_dataset(q, lens, img_pos, ans, feats, img_norm=True)
+    if world > 1:
+        ids = [tr.ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        tr.ctx.comm_init(rank, world, ids[0])
+    fn = feats / np.sqrt((feats * feats).sum(1, keepdims=True)) if host_batches else None
+
+    def barrier():
+        tr.ctx.sync()
+        torch.cuda.synchronize(local_rank)
+        if dist:
+            dist.barrier()
+
+    def one_step():
+        if host_batches:
+            qi = tr.next_batch()
+            tr.ctx.step(q[qi], lens[qi] if w["arch"] == 1 else None, fn[img_pos[qi] - 1], ans[qi], tr._dropout(), want_loss=False)
+        else:
+            tr.ctx.step_indices(tr.next_batch(), tr._dropout(), want_loss=False)
+        tr.rmsprop()
+
+    for _ in range(warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss = tr.ctx.get_loss()
+
+    fl_qa = flops_per_qa_actual(w, ragged)
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    value = w["B"] * world * steps / dt
+    out = {"value": round(value, 1), "ms_per_step": round(1e3 * dt / steps, 4), "flop_per_qa": round(fl_qa),
+           "step_mfma_frac": round(value * fl_qa / (world * peak * 1e12), 4), "final_loss": round(loss, 5)}
+    if roofline:
+        # per-kernel HIP-event timing on the library's stream, in a separate (untimed) pass;
+        # every rank runs the steps (the all-reduce needs them), rank 0 records
+        nprof = 3
+        if rank == 0:
+            tr.ctx.profile_enable(True)
+            tr.ctx.profile_reset()
+        for _ in range(nprof):
+            one_step()
+        tr.ctx.sync()
+        if rank == 0:
+            prof = tr.ctx.profile()
+            tr.ctx.profile_enable(False)
+            gemm = {k: v for k, v in prof.items() if v["flops"] > 0 and v["launches"] > 0}
+            dom = max(gemm, key=lambda k: gemm[k]["ms"])
+            pv = gemm[dom]
+            avg_ms = pv["ms"] / pv["launches"]
+            # the library books full-length FLOPs for the time-batched / recurrent products: scale to the rows that exist
+            lstm_part = dom.startswith("lstm") or dom in ("gemm_wgrad", "gemm_dgrad", "gemm_i2h_fwd")
+            scale = mean_len(w, ragged) / w["T"] if (ragged and w["arch"] == 1 and lstm_part) else 1.0
+            ach = scale * pv["flops"] / pv["launches"] / (avg_ms * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled as
+            # MI355X_MICROARCH.md prescribes, + WRITE_SIZE), recorded by tools/pmc_traffic.py under profiles/
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and not ragged and not bf16 and w is WORKLOAD:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": traffic,
+                               "avg_launch_ms": round(avg_ms, 5),
+                               "launches_per_step": pv["launches"] // nprof}
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in prof.items()
+                                         if v["launches"]}
+    tr.close()
+    return out
+
+
+def bench_vgg(pkg, n=32, iters=4):
+    """VGG-16 fc7 extractor (001_prepro_img_vgg.lua), full 224x224 network, synthetic weights: images/s with host
+    images in and host features out (nvqa_vgg16_fc7 as the reference script would call it)."""
+    v = pkg.binding.Vgg16(0, 1, 224, max_batch=n)
+    rng = np.random.default_rng(0)
+    chans = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512]
+    parts, cin = [], 3
+    for c in chans:
+        parts += [rng.standard_normal(c * cin * 9, dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9))), np.zeros(c, np.float32)]
+        cin = c
+    for k in (25088, 4096):
+        parts += [rng.standard_normal(4096 * k, dtype=np.float32) * np.float32(np.sqrt(2.0 / k)), np.zeros(4096, np.float32)]
+    v.set_weights(np.concatenate(parts))
+    x = rng.uniform(-120, 130, (n, 3, 224, 224)).astype(np.float32)
+    v.fc7(x)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        v.fc7(x)
+    dt = (time.perf_counter() - t0) / iters
+    v.close()
+    tf = 30.93 * n / dt / 1e3
+    return {"value": round(n / dt, 1), "unit": "images/s", "batch": n, "ms_per_batch": round(dt * 1e3, 2),
+            "mfma_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "note": "host images in / host features out (PCIe inside the timed call)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (N = 1 only)")
     ap.add_argument("--ragged", action="store_true", help="secondary case: question lengths ~ U{3..26}")
     ap.add_argument("--arch", type=int, default=1, choices=(1, 2),
                     help="2 = secondary case: arch2 deeper LSTM + Inception feats (BASELINE configs[3])")
@@ -129,7 +267,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch
+    import torch  # noqa: F401  (device synchronisation in bench_one)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -140,103 +278,40 @@ def main():
 
     pkg = ge.load_package()
     w = WORKLOAD if args.arch == 1 else WORKLOAD_ARCH2
-    dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
-    try:
-        # rank: own sample ids and own dropout masks per rank; the parameter seed is common to all ranks
-        tr = pkg.trainer.VQATrainer(dims, device=local_rank, seed=123, rank=rank)
-    except pkg.binding.NvqaError as e:
-        print(f"bench.py rank {rank}/{world}: nvqa_create failed: {e}", file=sys.stderr, flush=True)
-        if dist:
-            dist.destroy_process_group()
-        raise SystemExit(3)
-    tr.init_params()  # same on every rank (counter-based)
-    if args.bf16:
-        tr.ctx.set_precision(1)
-    tr.load_dataset(*synth_dataset(w, 123, args.ragged), img_norm=True)
-    if world > 1:
-        ids = [tr.ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        tr.ctx.comm_init(rank, world, ids[0])
-
-    def barrier():
-        tr.ctx.sync()
-        torch.cuda.synchronize(local_rank)
-        if dist:
-            dist.barrier()
-
-    def one_step():
-        tr.ctx.step_indices(tr.next_batch(), tr._dropout(), want_loss=False)
-        tr.rmsprop()
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    loss = tr.ctx.get_loss()
-
-    fl_qa, _ = flops_per_qa(w)
-    peak = BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS
-    value = w["B"] * world * args.steps / dt
+    res = bench_one(pkg, w, args, rank, local_rank, world, dist, args.steps, args.warmup, ragged=args.ragged,
+                    bf16=args.bf16, roofline=not args.no_roofline)
     out = {
-        "metric": "QA-pairs/sec training step (batch 512, seq 26)" + ("" if args.arch == 1 else " [arch2, secondary]"), "value": round(value, 1),
+        "metric": "QA-pairs/sec training step (batch 512, seq 26)" + ("" if args.arch == 1 else " [arch2, secondary]"), "value": res["value"],
         "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 operands, f32 accumulate" if args.bf16 else "f32", "data": "synthetic",
         "config": {"workload": ("arch1 002_train_baseline: V=14773 E=200 R=512 L=2 I=4096 C=1024 A=1000, " if args.arch == 1 else
                                 "arch2 002_train_baseline (deeper LSTM + Inception feats): V=14773 E=R=512 L=2 I=2048 A=1000, 28 steps, wd 1e-4, ")
                                + ("lengths U{3..26}" if args.ragged else "all lengths 26") + ", dropout 0.5 on, HBM-resident dataset, RMSprop",
                    "global_batch": w["B"] * world, "seq_len": w["T"], "parallelism": f"dp{world}"},
-        "flop_per_qa": fl_qa,
-        "step_mfma_frac": round(value * fl_qa / (world * peak * 1e12), 4),
-        "final_loss": round(loss, 5),
     }
-
-    if not args.no_roofline:
-        # per-kernel HIP-event timing on the library's stream, in a separate (untimed) pass;
-        # every rank runs the steps (the all-reduce needs them), rank 0 records
-        nprof = 3
-        if rank == 0:
-            tr.ctx.profile_enable(True)
-            tr.ctx.profile_reset()
-        for _ in range(nprof):
-            one_step()
-        tr.ctx.sync()
-        if rank == 0:
-            prof = tr.ctx.profile()
-            tr.ctx.profile_enable(False)
-            gemm = {k: v for k, v in prof.items() if v["flops"] > 0 and v["launches"] > 0}
-            dom = max(gemm, key=lambda k: gemm[k]["ms"])
-            pv = gemm[dom]
-            avg_ms = pv["ms"] / pv["launches"]
-            ach = pv["flops"] / pv["launches"] / (avg_ms * 1e-3) / 1e12
-            # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled as
-            # MI355X_MICROARCH.md prescribes, + WRITE_SIZE), recorded by tools/pmc_traffic.py under profiles/
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None if args.bf16 else traffic,
-                               "avg_launch_ms": round(avg_ms, 5),
-                               "launches_per_step": pv["launches"] // nprof}
-            out["kernel_ms_per_step"] = {k: round(v["ms"] / nprof, 4) for k, v in prof.items()
-                                         if v["launches"]}
+    out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
     if dist:
         dist.barrier()
+    headline = args.arch == 1 and not args.ragged and not args.bf16
+    if rank == 0 and world == 1 and headline and not args.no_secondary:
+        # the other BASELINE.json configurations that fit one GPU, each with its own roofline fraction (10 timed steps)
+        sec = {}
+        def brief(r):
+            return {"value": r["value"], "unit": "QA-pairs/s", "ms_per_step": r["ms_per_step"], "step_mfma_frac": r["step_mfma_frac"],
+                    "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms")}}
+        sec["arch1_ragged_U3_26"] = brief(bench_one(pkg, WORKLOAD, args, 0, local_rank, 1, None, 10, 3, ragged=True))
+        sec["arch2_f32"] = brief(bench_one(pkg, WORKLOAD_ARCH2, args, 0, local_rank, 1, None, 10, 3))
+        sec["arch2_bf16"] = brief(bench_one(pkg, WORKLOAD_ARCH2, args, 0, local_rank, 1, None, 10, 3, bf16=True))
+        hb = bench_one(pkg, WORKLOAD, args, 0, local_rank, 1, None, 10, 3, roofline=False, host_batches=True)
+        sec["arch1_nvqa_step_host_batches"] = {"value": hb["value"], "unit": "QA-pairs/s", "ms_per_step": hb["ms_per_step"],
+                                               "note": "JdJ-shaped entry: host batch validated and copied (3 synchronous hipMemcpy) per call"}
+        sec["vgg16_fc7"] = bench_vgg(pkg)
+        out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    tr.close()
     if dist:
         dist.destroy_process_group()
 
