@@ -117,6 +117,18 @@ int nvqa_get_loss(nvqa_ctx *ctx, float *loss_out);
 int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t *lengths,
                  const float *img, float *scores_out, int32_t *argmax_out);
 
+/* Evaluate-mode forward with everything the reference's validation and test loops take from it, on the device:
+ *  labels [n] (optional, 1-based): *loss_out = mean cross-entropy over the n rows -- validate(),
+ *         002_train_baseline.lua:337-381 (arch2: 003_.../002_train_baseline.lua:335-378);
+ *  mc_ans [n x n_mc] (optional; 1-based answer ids, 0 = empty slot, n_mc <= 32): mc_argmax_out[i] = the candidate
+ *         with the highest score, first one on ties, as torch.max over the candidates in slot order gives it --
+ *         multiple-choice answers of 004_eval_model.lua:259-271 (MC_ans_test has 18 slots); rows without any
+ *         candidate return 0;
+ *  scores_out [n x A], argmax_out [n]: as nvqa_forward.  Every output pointer may be NULL. */
+int nvqa_evaluate(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t *lengths, const float *img,
+                  const int32_t *labels, const int32_t *mc_ans, int32_t n_mc, float *scores_out,
+                  int32_t *argmax_out, int32_t *mc_argmax_out, float *loss_out);
+
 /* clamp -> (+ wd * x) -> m = alpha m + (1-alpha) g^2 -> x -= lr g / (sqrt(m) + eps).
  * With a communicator (nvqa_comm_init) nvqa_step itself sums the gradient over the ranks,
  * one all-reduce per parameter segment overlapped with the backward pass; the update then

@@ -232,6 +232,27 @@ __global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, 
     }
 }
 
+// multiple-choice answer (004_eval_model.lua:259-271): among the non-zero candidate ids of a row, the one with the
+// highest score; ties go to the earlier slot (torch.max over the candidates in slot order).  One wave per row,
+// n_mc <= 64 candidates (the reference's MC_ans_test has 18).
+__global__ void k_mc_argmax(const float *scores, const int32_t *mc, int n, int A, int n_mc, int32_t *out)
+{
+    const int b = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (b >= n) return;
+    float v = -INFINITY;
+    int slot = 0x7fffffff;
+    if (lane < n_mc) {
+        const int a = mc[(size_t)b * n_mc + lane];
+        if (a >= 1 && a <= A) { v = scores[(size_t)b * A + (a - 1)]; slot = lane; }
+    }
+    const float mx = wave_max(v);
+    int cand = (slot != 0x7fffffff && v == mx) ? slot : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) out[b] = cand == 0x7fffffff ? 0 : mc[(size_t)b * n_mc + cand];
+}
+
 // mean of the row losses in a fixed order (single block -> bit-reproducible)
 __global__ void k_loss_mean(const float *rowloss, int B, float *loss)
 {

@@ -336,7 +336,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     comm_destroy(c);
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
-                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT,
+                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT, c->mc,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1136,6 +1136,44 @@ extern "C" int nvqa_forward(nvqa_ctx *c, int32_t n, const int32_t *tokens, const
     NVQA_TRY(check_persist(c));
     if (scores_out) NVQA_HIP(hipMemcpy(scores_out, c->scores, (size_t)n * c->d.A * 4, hipMemcpyDeviceToHost));
     if (argmax_out) NVQA_HIP(hipMemcpy(argmax_out, c->argmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nvqa_evaluate(nvqa_ctx *c, int32_t n, const int32_t *tokens, const int32_t *lengths, const float *img,
+                             const int32_t *labels, const int32_t *mc_ans, int32_t n_mc, float *scores_out,
+                             int32_t *argmax_out, int32_t *mc_argmax_out, float *loss_out)
+{
+    if (!c) { set_error("ctx is NULL"); return -1; }
+    if (mc_ans && (n_mc < 1 || n_mc > 64)) { set_error("n_mc=%d outside 1..64", n_mc); return -1; }
+    if ((loss_out && !labels) || (mc_argmax_out && !mc_ans)) { set_error("loss_out needs labels, mc_argmax_out needs mc_ans"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    NVQA_TRY(upload_batch(c, n, tokens, lengths, img, labels)); // validates tokens, lengths, labels
+    const nvqa_dims &d = c->d;
+    if (mc_ans) {
+        for (size_t i = 0; i < (size_t)n * n_mc; ++i)
+            if (mc_ans[i] < 0 || mc_ans[i] > d.A) { set_error("mc_ans[%zu]=%d outside 0..%d", i, mc_ans[i], d.A); return -1; }
+        if (!c->mc) NVQA_TRY(dalloc(&c->mc, (size_t)d.B * 64));
+        NVQA_HIP(hipMemcpy(c->mc, mc_ans, (size_t)n * n_mc * 4, hipMemcpyHostToDevice));
+    }
+    const Drop dr = mkdrop(nullptr, false);
+    if (d.arch == NVQA_ARCH1) NVQA_TRY(arch1_forward(c, dr, false, true));
+    else NVQA_TRY(arch2_forward(c, dr, false, true));
+    if (labels) { // mean cross-entropy of the first n rows (short batches are padded with copies of row 0)
+        hipLaunchKernelGGL(k_softmax_ce, dim3((d.B + 3) / 4), dim3(256), 0, c->s, c->scores, c->lab, d.B, d.A, (float *)nullptr,
+                           c->rowloss, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(256), 0, c->s, c->rowloss, n, c->d_loss);
+        NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
+    }
+    if (mc_ans) // reuses the dscores buffer's first n ints for the answers (training overwrites it every step)
+        hipLaunchKernelGGL(k_mc_argmax, dim3((n + 3) / 4), dim3(256), 0, c->s, c->scores, c->mc, n, d.A, n_mc,
+                           reinterpret_cast<int32_t *>(c->dscores));
+    NVQA_HIP(hipGetLastError());
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    NVQA_TRY(check_persist(c));
+    if (scores_out) NVQA_HIP(hipMemcpy(scores_out, c->scores, (size_t)n * d.A * 4, hipMemcpyDeviceToHost));
+    if (argmax_out) NVQA_HIP(hipMemcpy(argmax_out, c->argmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (mc_argmax_out) NVQA_HIP(hipMemcpy(mc_argmax_out, c->dscores, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (loss_out) *loss_out = *c->h_loss;
     return 0;
 }
 

@@ -116,6 +116,7 @@ struct nvqa_ctx {
     bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
+    int32_t *mc = nullptr;   // multiple-choice candidates of the batch being evaluated (nvqa_evaluate), allocated on first use
     float *h_loss = nullptr; // pinned
 
     nvqa::Dataset ds;

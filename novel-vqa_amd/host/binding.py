@@ -49,6 +49,8 @@ SYMBOLS = {
     "nvqa_step": (ctypes.c_int, [_vp, _i32p, _i32p, _f32p, _i32p, ctypes.POINTER(Dropout), _f32p]),
     "nvqa_get_loss": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_forward": (ctypes.c_int, [_vp, ctypes.c_int32, _i32p, _i32p, _f32p, _f32p, _i32p]),
+    "nvqa_evaluate": (ctypes.c_int, [_vp, ctypes.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, ctypes.c_int32, _f32p, _i32p,
+                                     _i32p, _f32p]),
     "nvqa_rmsprop_update": (ctypes.c_int, [_vp] + [ctypes.c_float] * 5),
     "nvqa_set_fusion": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -210,6 +212,29 @@ class Context:
         self._check(self.lib.nvqa_forward(self._h, n, _i32(tokens), _i32(lengths), _f32(img),
                                           _f32(scores), _i32(argmax)))
         return scores, argmax
+
+    def evaluate(self, tokens, lengths, img, labels=None, mc_ans=None):
+        """nvqa_evaluate: dict(scores, argmax, loss (if labels), mc_argmax (if mc_ans [n, n_mc], 0 = empty slot))."""
+        d = self.dims
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        n = tokens.shape[0]
+        lengths = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        img = np.ascontiguousarray(img, np.float32)
+        labels = None if labels is None else np.ascontiguousarray(labels, np.int32)
+        mc = None if mc_ans is None else np.ascontiguousarray(mc_ans, np.int32)
+        scores = np.empty((n, d.A), np.float32)
+        argmax = np.empty(n, np.int32)
+        mcout = np.empty(n, np.int32) if mc is not None else None
+        loss = ctypes.c_float(0)
+        self._check(self.lib.nvqa_evaluate(self._h, n, _i32(tokens), _i32(lengths), _f32(img), _i32(labels), _i32(mc),
+                                           0 if mc is None else mc.shape[1], _f32(scores), _i32(argmax), _i32(mcout),
+                                           ctypes.byref(loss) if labels is not None else None))
+        out = {"scores": scores, "argmax": argmax}
+        if labels is not None:
+            out["loss"] = float(loss.value)
+        if mc is not None:
+            out["mc_argmax"] = mcout
+        return out
 
     def rmsprop_update(self, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
         self._check(self.lib.nvqa_rmsprop_update(self._h, lr, alpha, eps, wd, clamp))

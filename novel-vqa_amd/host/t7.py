@@ -164,23 +164,72 @@ def load(path):
 SEGMENT_KEYS = {1: ("encoder_w_q", "embedding_w_q", "multimodal_w"), 2: ("cnn_w", "encoder_w_q", "multimodal_w")}
 
 
-def save_checkpoint(path, arch, params, segments):
-    """The reference's checkpoint table from the flat parameter vector (reference segment order)."""
+LAYOUT_MARK = "nvqa"   # written under the key 'layout': the LSTM tensors inside encoder_w_q are in include/nvqa_layout.h order
+
+
+def encoder_permutation(order, R, L, in0):
+    """Index permutation that maps an encoder_w_q whose per-layer tensors come in another order onto this library's
+    (W_i2h [4R x in], b_i2h [4R], W_h2h [4R x R], b_h2h [4R], layer after layer; in = in0 for layer 0, R above).
+    `order`: the foreign order as a sequence of (layer, name) with name in {'w_i2h', 'b_i2h', 'w_h2h', 'b_h2h'},
+    e.g. what nngraph's forward-node walk yields once it has been read off a Torch7 installation.  Returns perm with
+    ours = foreign[perm] (trailing entries beyond the LSTM tensors, e.g. arch2's lookup table, keep their place).
+    PARITY UNPINNED: no nngraph source or reference checkpoint is available offline to fix `order`."""
+    sizes = {}
+    for l in range(L):
+        inn = in0 if l == 0 else R
+        sizes[(l, "w_i2h")] = 4 * R * inn
+        sizes[(l, "b_i2h")] = 4 * R
+        sizes[(l, "w_h2h")] = 4 * R * R
+        sizes[(l, "b_h2h")] = 4 * R
+    order = [tuple(o) for o in order]
+    if sorted(order) != sorted(sizes):
+        raise ValueError("order must name every (layer, tensor) exactly once")
+    start, off = {}, 0
+    for key in order:
+        start[key] = off
+        off += sizes[key]
+    perm = []
+    for l in range(L):
+        for name in ("w_i2h", "b_i2h", "w_h2h", "b_h2h"):
+            perm.append(np.arange(start[(l, name)], start[(l, name)] + sizes[(l, name)], dtype=np.int64))
+    return np.concatenate(perm)
+
+
+def save_checkpoint(path, arch, params, segments, encoder_perm=None):
+    """The reference's checkpoint table from the flat parameter vector (reference segment order).  Without
+    encoder_perm the table is marked layout = 'nvqa' (this library's order inside encoder_w_q); with one
+    (ours = foreign[perm]) the encoder segment is written in the foreign order and no marker is set."""
     params = np.asarray(params, np.float32)
     out, off = {}, 0
     for k, n in zip(SEGMENT_KEYS[arch], segments):
         out[k] = params[off:off + n].copy()
         off += n
+    if encoder_perm is not None:
+        enc = out["encoder_w_q"]
+        foreign = enc.copy()
+        foreign[np.asarray(encoder_perm)] = enc[:len(encoder_perm)]
+        out["encoder_w_q"] = foreign
+    else:
+        out["layout"] = LAYOUT_MARK
     save(path, out)
 
 
-def load_checkpoint(path, arch, segments):
-    """Flat parameter vector from a reference checkpoint table (004_eval_model.lua:154-163)."""
+def load_checkpoint(path, arch, segments, encoder_perm=None):
+    """Flat parameter vector from a reference checkpoint table (004_eval_model.lua:154-163).  A table without the
+    layout = 'nvqa' marker is a foreign (Torch7 / nngraph-ordered) file: loading it as is would put LSTM weights
+    into the wrong tensors without any error, so it is refused unless encoder_perm (ours = foreign[perm], see
+    encoder_permutation) says how its encoder segment is ordered."""
     t = load(path)
+    if t.get("layout") != LAYOUT_MARK and encoder_perm is None:
+        raise ValueError("checkpoint has no layout = 'nvqa' marker: the order of the LSTM tensors inside encoder_w_q is "
+                         "unknown (nngraph forward-node order); pass encoder_perm = t7.encoder_permutation(...)")
     parts = []
     for k, n in zip(SEGMENT_KEYS[arch], segments):
         a = np.asarray(t[k], np.float32).ravel()
         if a.size != n:
             raise ValueError(f"{k}: checkpoint has {a.size} values, the model wants {n}")
+        if k == "encoder_w_q" and encoder_perm is not None:
+            a = a.copy()
+            a[:len(encoder_perm)] = a[np.asarray(encoder_perm)]
         parts.append(a)
     return np.concatenate(parts)

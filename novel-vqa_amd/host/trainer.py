@@ -23,7 +23,7 @@ DECAY_FACTOR = 0.99997592083  # 002_train_baseline.lua:78
 
 class VQATrainer:
     def __init__(self, dims, device=0, learning_rate=3e-4, alpha=0.99, epsilon=1e-8,
-                 weight_decay=None, clamp=10.0, seed=123, dropout_p=0.5, dropout=True, rank=0):
+                 weight_decay=None, clamp=10.0, seed=123, dropout_p=0.5, dropout=True, rank=0, ref_quirks=0):
         self.dims = dims
         self.ctx = binding.Context(dims, device)
         self.learningRate = learning_rate
@@ -41,6 +41,10 @@ class VQATrainer:
         self.running_avg = None
         self.rng = np.random.default_rng(seed + 1000 * rank)  # each rank draws its own sample ids
         self.n_questions = 0
+        # arch2: 3 reproduces what 003_train_vqa_arch2/002_train_baseline.lua really trains (aliased top-layer h0 + lookup
+        # table without gradient, include/nvqa.h nvqa_set_ref_quirks) -- lua/train_arch2.lua's default; 0 = the model as designed
+        if dims.arch == 2 and ref_quirks:
+            self.ctx.set_ref_quirks(ref_quirks)
 
     # -- parameters (join_vector({encoder_w_q, embedding_w_q, multimodal_w})) ---------------
     def init_params(self, lo=-0.08, hi=0.08):
@@ -103,12 +107,44 @@ class VQATrainer:
             preds.append(am)
         return np.concatenate(scores), np.concatenate(preds)
 
+    def validate(self, tokens, lengths, img, labels):
+        """validate() of the training scripts (002_train_baseline.lua:337-381; arch2 :335-378): evaluate-mode forward
+        over the validation split in batches of B (the last one short), f_avg = mean of the per-batch mean
+        cross-entropies, and the same 0.95 / 0.05 running average the scripts log."""
+        tokens = np.asarray(tokens)
+        B, n = self.dims.B, np.asarray(tokens).shape[0]
+        f_sum, iters = 0.0, 0
+        for s in range(0, n, B):
+            r = self.ctx.evaluate(tokens[s:s + B], None if lengths is None else lengths[s:s + B], img[s:s + B],
+                                  labels=labels[s:s + B])
+            f = r["loss"]
+            self.running_avg_val = f if getattr(self, "running_avg_val", None) is None else self.running_avg_val * 0.95 + f * 0.05
+            f_sum += f
+            iters += 1
+        return f_sum / max(iters, 1)
+
+    def predict_mc(self, tokens, lengths, img, mc_ans):
+        """Open-ended argmax and multiple-choice answer ids (004_eval_model.lua:233,259-271), both taken on the device."""
+        tokens = np.asarray(tokens)
+        B = self.dims.B
+        pred, mc = [], []
+        for s in range(0, tokens.shape[0], B):
+            r = self.ctx.evaluate(tokens[s:s + B], None if lengths is None else lengths[s:s + B], img[s:s + B],
+                                  mc_ans=np.asarray(mc_ans)[s:s + B])
+            pred.append(r["argmax"])
+            mc.append(r["mc_argmax"])
+        return np.concatenate(pred), np.concatenate(mc)
+
     # -- torch.save / torch.load of the reference's checkpoint table (:401-402, 004_eval_model.lua:154-163)
+    # PARITY UNPINNED: the order of the LSTM tensors INSIDE encoder_w_q is this package's (include/nvqa_layout.h), not
+    # nngraph's forward-node order, which cannot be established offline (no nngraph source, no reference .t7).  Files
+    # written here carry layout = 'nvqa'; a file without the marker (a genuine Torch7 checkpoint) is refused unless
+    # the caller supplies the permutation (host/t7.py: encoder_permutation).
     def save_checkpoint(self, path):
         t7.save_checkpoint(path, self.dims.arch, self.get_params(), self.ctx.segments())
 
-    def load_checkpoint(self, path):
-        self.set_params(t7.load_checkpoint(path, self.dims.arch, self.ctx.segments()))
+    def load_checkpoint(self, path, encoder_perm=None):
+        self.set_params(t7.load_checkpoint(path, self.dims.arch, self.ctx.segments(), encoder_perm=encoder_perm))
 
     def close(self):
         self.ctx.close()

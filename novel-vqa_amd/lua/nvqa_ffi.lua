@@ -28,6 +28,9 @@ int nvqa_step(nvqa_ctx *ctx, const int32_t *tokens, const int32_t *lengths, cons
 int nvqa_get_loss(nvqa_ctx *ctx, float *loss_out);
 int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t *lengths,
                  const float *img, float *scores_out, int32_t *argmax_out);
+int nvqa_evaluate(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t *lengths, const float *img,
+                  const int32_t *labels, const int32_t *mc_ans, int32_t n_mc, float *scores_out,
+                  int32_t *argmax_out, int32_t *mc_argmax_out, float *loss_out);
 int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
 int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
 int nvqa_set_precision(nvqa_ctx *ctx, int bf16);

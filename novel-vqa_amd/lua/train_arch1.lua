@@ -42,14 +42,26 @@ local question = h5:read('/ques_train'):all():int()
 local lengths  = h5:read('/ques_length_train'):all():int()
 local img_list = h5:read('/img_pos_train'):all():int()
 local answers  = h5:read('/answers'):all():int()
+local question_val = h5:read('/ques_val'):all():int()                               -- :98-101
+local lengths_val  = h5:read('/ques_length_val'):all():int()
+local img_list_val = h5:read('/img_pos_val'):all():long()
+local answers_val  = h5:read('/answers_val'):all():int()
 h5:close()
-h5 = hdf5.open(opt.input_img_h5, 'r'); local fv_im = h5:read('/images_train'):all():float(); h5:close()
+h5 = hdf5.open(opt.input_img_h5, 'r')
+local fv_im = h5:read('/images_train'):all():float()
+local fv_im_val = h5:read('/images_val'):all():float()                             -- :109
+h5:close()
 local function right_align(seq, len)                       -- misc/RNNUtils.lua:54-61
   local v = seq:clone():fill(0); local N = seq:size(2)
   for i = 1, seq:size(1) do v[i][{{N-len[i]+1,N}}] = seq[i][{{1,len[i]}}] end
   return v
 end
 question = right_align(question, lengths):contiguous()
+question_val = right_align(question_val, lengths_val):contiguous()                  -- :114
+if opt.img_norm == 1 then                                                           -- :119-121 (the training features are normalised on the device)
+  local nm = torch.sqrt(torch.sum(torch.cmul(fv_im_val, fv_im_val), 2))
+  fv_im_val = torch.cdiv(fv_im_val, torch.repeatTensor(nm, 1, opt.nhimage)):float()
+end
 local vocabulary_size_q = 0
 for _ in pairs(json_file['ix_to_word']) do vocabulary_size_q = vocabulary_size_q + 1 end
 
@@ -64,6 +76,27 @@ local loss = require('ffi').new('float[1]')
 local running_avg
 paths.mkdir(opt.checkpoint_path .. 'save')
 local fileLogger = io.open(opt.checkpoint_path .. 'save/logFile.txt', 'w')
+local fileLoggerVal = io.open(opt.checkpoint_path .. 'save/logFileVal.txt', 'w')
+
+-- validate() (:337-381): evaluate-mode forward over the validation split, batch by batch (the last one short);
+-- f_avg = mean of the per-batch mean cross-entropies, running_avg_val as the script keeps it
+local running_avg_val
+local function validate()
+  local nval, B = question_val:size(1), opt.batch_size
+  local f_avg, iters, f = 0, 0, require('ffi').new('float[1]')
+  for i = 1, nval, B do
+    local r = math.min(i + B - 1, nval)
+    local q = question_val[{{i, r}}]:contiguous()
+    local l = lengths_val[{{i, r}}]:contiguous()
+    local im = fv_im_val:index(1, img_list_val[{{i, r}}]):contiguous()
+    local y = answers_val[{{i, r}}]:contiguous()
+    nvqa.check(nvqa.lib.nvqa_evaluate(ctx, r - i + 1, nvqa.iptr(q), nvqa.iptr(l), nvqa.fptr(im), nvqa.iptr(y),
+               nil, 0, nil, nil, nil, f))
+    running_avg_val = running_avg_val and (running_avg_val*0.95 + f[0]*0.05) or f[0]
+    f_avg = f_avg + f[0]; iters = iters + 1
+  end
+  return f_avg / iters
+end
 
 local function save(path)                                                           -- :401-402
   local n = tonumber(nvqa.lib.nvqa_param_count(ctx))
@@ -76,7 +109,12 @@ local function save(path)                                                       
 end
 
 for iter = 1, opt.max_iters do
-  if iter % opt.save_checkpoint_every == 0 then save(string.format(opt.checkpoint_path..'save/lstm_save_iter%d.t7', iter)) end
+  if iter % opt.save_checkpoint_every == 0 or iter == 1 then                        -- :395-403
+    local loss_val = validate()
+    fileLoggerVal:write('validation loss: ' .. loss_val .. ' validation loss avg: ' .. running_avg_val, ' on iter: ' .. iter .. '/' .. opt.max_iters .. '\n')
+    print('validation loss: ' .. loss_val .. ' validation loss avg: ' .. running_avg_val .. ' on iter: ' .. iter .. '/' .. opt.max_iters .. '\n')
+    save(string.format(opt.checkpoint_path..'save/lstm_save_iter%d.t7', iter))
+  end
   -- dataset:next_batch(): qinds[i] = torch.random(nqs)  (:202-205); the gather runs on the device
   local qinds = torch.LongTensor(opt.batch_size):random(question:size(1)):add(-1)
   -- JdJ + optim.rmsprop  (:272-335, :408)
@@ -90,4 +128,5 @@ for iter = 1, opt.max_iters do
   optimize.learningRate = optimize.learningRate * decay_factor                      -- :410
 end
 fileLogger:close()
+fileLoggerVal:close()
 save(opt.checkpoint_path .. 'lstm.t7')

@@ -1,1 +1,2 @@
-python bench.py --steps 20 --warmup 5 > gpurun_out/r2_bench3.log 2>&1; tail -c 4500 gpurun_out/r2_bench3.log
+python bench.py --steps 10 --warmup 3 --arch 2 --bf16 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['kernel_ms_per_step'])"
+python bench.py --steps 10 --warmup 3 --arch 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['kernel_ms_per_step'])"

@@ -82,3 +82,33 @@ def test_late_fusion_and_results_json(pkg):
     assert s.argmax(1).tolist() == [0, 0]
     r = pkg.trainer.results_json([11, 12], [2, 1], {"1": "yes", "2": "no"})
     assert r == [{"question_id": 11, "answer": "no"}, {"question_id": 12, "answer": "yes"}]
+
+
+def test_evaluate_validation_loss_and_multiple_choice(pkg, orc):
+    """nvqa_evaluate = what validate() (002_train_baseline.lua:337-381) and the test script (004_eval_model.lua:233,
+    259-271) take from an evaluate-mode forward: mean cross-entropy of the rows, open-ended argmax, and the
+    multiple-choice answer among the non-zero candidates (first on ties, as torch.max over the slot order)."""
+    for kw in (dict(arch=1, B=24, T=7, V=40, E=16, R=16, L=2, I=32, C=24, A=30),
+               dict(arch=2, B=24, T=6, V=40, E=16, R=16, L=1, I=32, C=4, A=30)):
+        d = orc.make_dims(**kw)
+        params = orc.synth_params(d) * np.float32(3.0)
+        tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+        lens = lens if d.arch == 1 else None
+        rng = np.random.default_rng(2)
+        mc = rng.integers(0, d.A + 1, (d.B, 18)).astype(np.int32)   # 0 = empty slot
+        mc[3] = 0                                                    # a row without candidates
+        mc[5, :] = mc[5, 0] if mc[5, 0] else 7                       # all slots the same answer: a tie
+        ctx = pkg.binding.Context(gdims(pkg, d), 0)
+        ctx.set_params(params)
+        for n in (d.B, 9):                                           # full batch and a short last batch
+            sl = slice(0, n)
+            dn = orc.make_dims(**{**kw, "B": n})
+            ref = orc.Oracle(np.float64).step(dn, params, tok[sl], None if lens is None else lens[sl], img[sl], lab[sl], None, train=False)
+            r = ctx.evaluate(tok[sl], None if lens is None else lens[sl], img[sl], labels=lab[sl], mc_ans=mc[sl])
+            assert abs(r["loss"] - ref["loss"]) <= 2e-6 * abs(ref["loss"])
+            assert np.array_equal(r["argmax"], ref["argmax"])
+            exp = pkg.trainer.multiple_choice_argmax(ref["scores"][[i for i in range(n) if mc[i].any()]], mc[[i for i in range(n) if mc[i].any()]])
+            got = r["mc_argmax"]
+            assert np.array_equal(got[[i for i in range(n) if mc[i].any()]], exp)
+            assert all(got[i] == 0 for i in range(n) if not mc[i].any())
+        ctx.close()

@@ -38,5 +38,32 @@ def test_round_trip_and_checkpoint(pkg, tmp_path):
         q = tmp_path / f"ck{arch}.t7"
         pkg.t7.save_checkpoint(str(q), arch, x, seg)
         t = pkg.t7.load(str(q))
-        assert sorted(t) == sorted(pkg.t7.SEGMENT_KEYS[arch])
+        assert sorted(t) == sorted(pkg.t7.SEGMENT_KEYS[arch] + ("layout",)) and t["layout"] == "nvqa"
         assert np.array_equal(pkg.t7.load_checkpoint(str(q), arch, seg), x)
+
+
+def test_foreign_checkpoint_needs_a_permutation(pkg, orc, tmp_path):
+    """A table without the layout marker (what Torch7 itself writes) is refused; with the order of its LSTM tensors
+    given, encoder_w_q is permuted into this library's order -- and written back in the foreign order."""
+    import pytest
+    R, L, E = 4, 2, 8
+    d = orc.make_dims(arch=1, B=2, T=3, V=5, E=E, R=R, L=L, I=4, C=4, A=4)
+    lo = orc.layout(d)
+    segs = lo["_segments"]
+    ours = np.arange(lo["_total"], dtype=np.float32)
+    # a foreign file: per layer h2h before i2h, weights before biases (a stand-in for nngraph's node order)
+    order = [(l, n) for l in range(L) for n in ("w_h2h", "w_i2h", "b_h2h", "b_i2h")]
+    enc = ours[:segs[0]]
+    pieces = {(l, n): enc[lo[f"{n}{l}"][0]:lo[f"{n}{l}"][0] + lo[f"{n}{l}"][1]] for l in range(L) for n in ("w_i2h", "b_i2h", "w_h2h", "b_h2h")}
+    foreign_enc = np.concatenate([pieces[k] for k in order])
+    p = tmp_path / "torch7.t7"
+    pkg.t7.save(str(p), {"encoder_w_q": foreign_enc, "embedding_w_q": ours[segs[0]:segs[0] + segs[1]],
+                          "multimodal_w": ours[segs[0] + segs[1]:]})
+    with pytest.raises(ValueError, match="layout"):
+        pkg.t7.load_checkpoint(str(p), 1, segs)
+    perm = pkg.t7.encoder_permutation(order, R, L, E)
+    assert np.array_equal(pkg.t7.load_checkpoint(str(p), 1, segs, encoder_perm=perm), ours)
+    q = tmp_path / "back.t7"
+    pkg.t7.save_checkpoint(str(q), 1, ours, segs, encoder_perm=perm)
+    t = pkg.t7.load(str(q))
+    assert "layout" not in t and np.array_equal(t["encoder_w_q"], foreign_enc)
