@@ -18,6 +18,7 @@
 #include "gemm_ring.h"
 #include "kernels.h"
 #include "lstm_persist.h"
+#include "lstm_persist_bwd.h"
 #include "nvqa_ctx.h"
 
 using namespace nvqa;
@@ -318,8 +319,20 @@ static int create_impl(nvqa_ctx *c)
         c->num_cus = prop.multiProcessorCount;
         c->pf_cnt_words = ((size_t)L * ((B + 63) / 64) * TS + 4 + 3) / 4 * 4; // counters for the finest row blocking + err word, 16-byte multiple
         NVQA_TRY(dalloc(&c->pf_cnt, c->pf_cnt_words));
-        NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 4 * sizeof(unsigned), hipHostMallocDefault));
-        memset(c->h_pf_err, 0, 16);
+        NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 8 * sizeof(unsigned), hipHostMallocDefault));
+        memset(c->h_pf_err, 0, 32);
+        // persistent BPTT (lstm_persist_bwd.h): opt-in with NVQA_PERSIST_BWD=1 -- parity-green, but at 46 us per step it
+        // only ties the per-level kernels (33.5 + 8.2 us): its serial part per step (counter wait 4 us, pipeline prologue
+        // 2 us, K-quarter reduction + cell backward + write-through drain 9 us) cannot hide behind an independent K
+        // segment the way the forward kernel's does
+        const char *eb = getenv("NVQA_PERSIST_BWD");
+        c->persist_bwd_on = eb && eb[0] == '1';
+        if (d.R == 512 && L <= 2) {
+            const size_t rbmax = (B + 63) / 64;
+            c->pb_cnt_words = (L * rbmax * TS * (1 + R / 32) + 4 + 3) / 4 * 4;
+            NVQA_TRY(dalloc(&c->pb_cnt, c->pb_cnt_words));
+            if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
+        }
     }
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
@@ -349,6 +362,8 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->h_loss) (void)hipHostFree(c->h_loss);
     if (c->h_pf_err) (void)hipHostFree(c->h_pf_err);
     if (c->pf_cnt) (void)hipFree(c->pf_cnt);
+    if (c->pb_cnt) (void)hipFree(c->pb_cnt);
+    if (c->pb_pup) (void)hipFree(c->pb_pup);
     for (hipEvent_t e : {c->evComm, c->evStart})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evSeg)
@@ -362,6 +377,13 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
 // after the stream has drained: did a persistent-kernel wait give up? (lstm_persist.h: every spin is bounded)
 static int check_persist(nvqa_ctx *c)
 {
+    if (c->h_pf_err && c->h_pf_err[4]) {
+        set_error("persistent BPTT kernel: workgroup %u timed out waiting (code 0x%x, value seen %u); results of that step are invalid",
+                  c->h_pf_err[7], c->h_pf_err[4], c->h_pf_err[6]);
+        memset(c->h_pf_err + 4, 0, 16);
+        c->persist_bwd_on = false; // later steps take the per-level path
+        return -3;
+    }
     if (c->h_pf_err && *c->h_pf_err) {
         // word index relative to the err word: counters end 4 words before it
         const long widx = (long)(int)c->h_pf_err[1] + (long)c->pf_cnt_words - 4;
@@ -680,10 +702,76 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 // and (dX0 != NULL) dX0 holds dL/d(layer-0 input).  Same wavefront as the forward pass, top
 // layer first; the time-batched weight-gradient GEMMs of a layer start on the low-priority
 // bulk stream as soon as that layer's last step is done.
+// BPTT as one persistent launch (lstm_persist_bwd.h): same eligibility as the forward kernel, L <= 2.
+static int persist_bwd_rows(const nvqa_ctx *c, int *RB)
+{
+    const nvqa_dims &d = c->d;
+    if (!persist_rows(c) || !c->persist_bwd_on || d.L > 2) return 0;
+    const int mtiles = (d.B + 15) / 16, NU = d.R / 32, MT = d.L == 1 ? 4 : 7;
+    *RB = (mtiles + MT - 1) / MT;
+    if ((2 * d.L - 1) * *RB * NU > c->num_cus || c->num_cus < 256 || (2 * d.L - 1) * *RB > 8 * (32 / NU)) return 0;
+    return MT;
+}
+
+template <int GK, int MT>
+static int launch_persist_bwd(nvqa_ctx *c, const PersistBwdArgs &a, int grid)
+{
+    const size_t lds = PersistBwdGeom<GK, MT>::LDS_BYTES;
+    static int resident = -1;
+    if (resident < 0) {
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_bwd_persist<GK, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nb = 0;
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_bwd_persist<GK, MT>, NVQA_PF_THREADS, lds));
+        resident = nb;
+    }
+    if (resident < 1 || grid > c->num_cus) {
+        set_error("persistent BPTT kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
+        return -1;
+    }
+    hipLaunchKernelGGL((k_lstm_bwd_persist<GK, MT>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+static int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, R = d.R, L = d.L, TS = c->TS;
+    PersistBwdArgs a = {};
+    for (int l = 0; l < L; ++l) {
+        a.Wh[l] = c->P + c->lo.w_h2h[l]; a.Wi[l] = c->P + c->lo.w_i2h[l];
+        a.Gt[l] = c->Gt[l]; a.Cs[l] = c->Cs[l];
+        a.Pup[l] = l + 1 < L ? c->pb_pup + (size_t)l * TS * B * R : nullptr;
+    }
+    a.dCT = c->dCT; a.dHT = c->dHT;
+    a.nrows = c->nrows; a.sort_idx = c->sort_idx;
+    a.tlast = d.arch == NVQA_ARCH2 ? c->tinfo + 1 : nullptr;
+    a.B = B; a.R = R; a.L = L; a.TS = TS; a.RB = RB; a.NU = R / 32;
+    a.dr = dr;
+    { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
+    { static const int dbg = [] { const char *e = getenv("NVQA_PB_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+    const size_t n_rec = (size_t)L * RB * TS, n_up = (size_t)L * RB * a.NU * TS;
+    if (n_rec + n_up + 4 > c->pb_cnt_words) { set_error("persistent BPTT: counter block too small"); return -1; }
+    a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = c->pb_cnt + c->pb_cnt_words - 4;
+    const int grid = 256; // 8 XCDs x 32 slots (lstm_persist_bwd.h maps groups to XCDs); (2L-1) * RB * NU of them have work
+    double flops = 0;
+    for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * R * ((double)(TS - 1) + (l + 1 < L ? TS : 0));
+    ProfScope ps(c, PF_LSTM_BWD, flops, 0);
+    NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
+    if (MT == 4) NVQA_TRY((launch_persist_bwd<32, 4>(c, a, grid)));
+    else NVQA_TRY((launch_persist_bwd<32, 7>(c, a, grid)));
+    NVQA_HIP(hipMemcpyAsync(c->h_pf_err + 4, a.err, 16, hipMemcpyDeviceToHost, c->s));
+    return 0;
+}
+
 static int lstm_backward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
+    {
+        int RB = 0;
+        if (const int MT = persist_bwd_rows(c, &RB)) return lstm_backward_persist(c, dr, MT, RB);
+    }
     const bool ring = c->use_ring && !c->bf16;
     const size_t wt = (size_t)4 * R * R;
     if (ring) { // W_h2h^l [4R][R] -> [R][4R], W_i2h^l (l >= 1) likewise: the level products become K-contiguous x K-contiguous

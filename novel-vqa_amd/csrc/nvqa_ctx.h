@@ -112,7 +112,11 @@ struct nvqa_ctx {
     int num_cus = 0;
     unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed before every launch)
     size_t pf_cnt_words = 0;
-    unsigned *h_pf_err = nullptr; // pinned copy of the err word
+    unsigned *h_pf_err = nullptr; // pinned copies of the err records (forward: words 0-3, BPTT: words 4-7)
+    bool persist_bwd_on = false;  // BPTT as one persistent launch (lstm_persist_bwd.h)
+    unsigned *pb_cnt = nullptr;   // its counters + err record
+    size_t pb_cnt_words = 0;
+    float *pb_pup = nullptr;      // [L-1][TS*B][R] products handed from the UP role to the cells of the layer below
     bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;

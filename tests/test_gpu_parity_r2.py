@@ -266,3 +266,20 @@ def test_persistent_forward_lstm(pkg, orc, name):
     g2 = ctx.get_grads()
     assert l1 == l2 and np.array_equal(g1, g2)
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["arch1_all26", "arch2_L2", "arch2_L1"])
+def test_persistent_bptt_opt_in(pkg, orc, name):
+    """NVQA_PERSIST_BWD=1: BPTT as one persistent launch with three workgroup roles (csrc/lstm_persist_bwd.h) -- not the
+    default (it only ties the per-level kernels), kept parity-green against the f64 oracle."""
+    kw, full, _ = PERSIST_CASES[name]
+    d = orc.make_dims(**kw)
+    params = orc.synth_params(d)
+    ctx = _ctx(pkg, d, {"NVQA_PERSIST_BWD": "1"})
+    ctx.set_params(params)
+    for it, seed in enumerate((123, 77)):
+        b = orc.synth_batch(d, seed=seed, full_length=full, min_len=3)
+        if d.arch == 2 and it:
+            b[0][:, 11:] = 0
+        _check_step(pkg, orc, d, ctx, params, b, orc.Dropout(1, 0.5, 123, 20 + it), TOL_GRAD, f"persist_bwd_{name}_{it}")
+    ctx.close()
