@@ -15,7 +15,7 @@ import json
 import sys
 
 GROUPS = [
-    ("lstm_step_fwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiLstmFwd" in n),
+    ("lstm_step_fwd", lambda n: "k_lstm_fwd_persist" in n or ("gemm_f32_multi_kernel" in n and "EpiLstmFwd" in n)),
     ("lstm_step_bwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiStore" in n),
     ("lstm_bwd_finish", lambda n: "k_lstm_bwd_finish" in n),
     ("gemm_wgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n),
