@@ -43,6 +43,10 @@ struct PersistFwdArgs {
     float *U[NVQA_PF_MAXL]; // U[l], l >= 1: [TS*B][R] Dropout(h^{l-1}) = input of layer l
     float *Hs[NVQA_PF_MAXL], *Cs[NVQA_PF_MAXL]; // [(TS+1)*B][R]; slice 0 = initial state
     float *Gt[NVQA_PF_MAXL];                    // [TS*B][4R] activated gates (kept for BPTT)
+    // bf16 instance only: bf16 images of Hs / U, written next to the f32 ones by the cell epilogue and read back by the
+    // K chunks (the f32 buffers stay what the backward pass and the head read).  The step is bound by the activation
+    // bytes every workgroup pulls per step (B x K per (layer, unit tile)), not by its 16x cheaper MFMAs: half the bytes.
+    unsigned short *Hb[NVQA_PF_MAXL], *Ub[NVQA_PF_MAXL];
     const int *nrows, *sort_idx;
     unsigned *cnt; // [L][RB][TS] arrival counters, zeroed before the launch
     unsigned *err; // != 0: a spin timed out (the launch still drains)
@@ -50,6 +54,7 @@ struct PersistFwdArgs {
     unsigned spin_limit; // polls before a wave gives up (NVQA_PF_SPIN_LIMIT unless NVQA_PF_SPIN overrides it)
     int dbg;       // measurement only (NVQA_PF_DBG): 1 no flag waits, 2 no cell math / stores, 8 activation loads without
                    // memory traffic, 16 libdevice instead of hardware exp / rcp in the cell
+    unsigned long long *ts; // dbg & 32: per workgroup {start, weights resident, steps done} in 100 MHz ticks (tools/pfdbg.sh)
     int h0_top;    // arch2 NVQA_QUIRK_H0: the top layer's h_{-1} (slice 0 of Hs) is live at step 0
     Drop dr;
 };
@@ -90,25 +95,47 @@ __device__ __forceinline__ bool pf_wait_ge(unsigned *word, unsigned want, unsign
     }
 }
 
-template <int G0, int G1, int MT> struct PersistGeom {
-    static constexpr int ROWS = 16 * MT, NC0 = (G0 + 3) / 4, NC1 = G1 / 4, NT = NC0 + NC1, NST = 3;
-    static constexpr int STAGE = ROWS * 64;                       // floats per ring stage
-    static constexpr size_t LDS_BYTES = (size_t)(NST + 1) * STAGE * 4 + 16; // ring + gate staging + flag word
+// A "group" is the K extent of one A-fragment read (ds_read_b128): f32: 16 k = 4 x v_mfma_f32_16x16x4_f32 per row tile;
+// BF (nvqa_set_precision(1): operands rounded to bf16, f32 accumulate): 32 k = ONE v_mfma_f32_16x16x32_bf16 (the gfx950
+// form).  A chunk (one ring stage, one barrier) is always 64 k: 4 groups in f32, 2 in bf16; the bf16 LDS image is half
+// the bytes (the float4 a thread staged is rounded with v_cvt_pk_bf16_f32 on its way into LDS), the resident weights are
+// half the registers (4 packed registers per group of 32 k).
+template <int G0, int G1, int MT, bool BF> struct PersistGeom {
+    static constexpr int GPC = BF ? 2 : 4;                        // groups per 64-deep chunk
+    static constexpr int ROWS = 16 * MT, NC0 = (G0 + GPC - 1) / GPC, NC1 = G1 / GPC, NT = NC0 + NC1, NST = 3;
+    static constexpr int STAGE = ROWS * (BF ? 32 : 64);           // floats per ring stage
+    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + ROWS * 64) * 4 + 16; // ring + gate staging
 };
+typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pf_pack_bf16(float x, float y) // round-to-nearest-even, like the level kernels' BF mode
+{
+    const pf_f32x2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pf_bf16x2));
+}
 
-// G0: 16-wide K groups of the input segment (ceil(Kin / 16)); G1 = R / 16 groups of the recurrent segment; MT row
+// G0 / G1: K groups of the input / recurrent segment (ceil(Kin / KG), R / KG with KG = 16 (f32) or 32 (bf16)); MT row
 // tiles of 16 rows per workgroup.
-template <int G0, int G1, int MT>
+// INB: the input segment is read from a bf16 image (layers >= 1 of the bf16 instance: Ub); the recurrent segment is
+// (Hb) whenever BF.
+template <int G0, int G1, int MT, bool BF, bool INB>
 __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const int l, const int rb, const int ut,
                                                   float *smem)
 {
-    typedef PersistGeom<G0, G1, MT> GE;
-    static_assert(G1 % 4 == 0, "R must be a multiple of 64");
-    static_assert(GE::NT % 2 == 0, "chunks per step must be even (static staging-register sets across steps)");
-    static_assert(GE::NC0 >= 3, "the first recurrent chunk (and the poll for it, a chunk earlier) must be requested after the previous step's epilogue");
+    typedef PersistGeom<G0, G1, MT, BF> GE;
+    constexpr int GPC = GE::GPC, KG = 64 / GPC;
+    static_assert(G1 % GPC == 0, "R must be a multiple of 64");
+    // D: chunks between a chunk's loads and its multiplication (= staging-register sets).  f32: a chunk is 1.7 us of MFMAs,
+    // two of them cover the L2 round trip.  bf16: 0.1 us -- the step is a chain of load latencies, 16 / D of them, so as
+    // deep as the input segment allows (the first recurrent chunk, and the poll for it a chunk earlier, must be requested
+    // after the previous step's epilogue: NC0 >= D + 1).
+    constexpr int D = !BF ? 2 : (GE::NC0 >= 5 ? 4 : 3);
+    static_assert(GE::NT % D == 0, "chunks per step must be a multiple of the prefetch distance (static staging-register sets across steps)");
+    static_assert(GE::NC0 >= D + 1, "the first recurrent chunk (and the poll for it, a chunk earlier) must be requested after the previous step's epilogue");
     constexpr int ROWS = GE::ROWS, NC0 = GE::NC0, NT = GE::NT, NST = GE::NST, STAGE = GE::STAGE;
     float *const ring = smem;               // [NST][ROWS][64], 16-byte chunks XOR-swizzled by the row
-    float *const Sg = smem + NST * STAGE;   // [ROWS][4 gates][16 units] pre-activations of the step
+    float *const Sg = smem + NST * STAGE;   // [ROWS][4 gates][16 units] pre-activations of the step (f32 in both modes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS;
     const int Kin = l == 0 ? a.E : R;
@@ -122,22 +149,30 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     // ---- weights of gate `wave`, units u0 .. u0+15, all of K: B fragments, resident for the whole launch ----------
     // MFMA 16x16x4: lane (li, lh) supplies B[k = lh][n = li]; with the A fragments read as 4 consecutive k per lane
     // (one ds_read_b128 per 16-wide group) the k of MFMA w in group g is 16 g + 4 lh + w for A and B alike.
-    float bw[(G0 + G1) * 4];
+    // (bf16: MFMA 16x16x32: lane (li, lh) supplies B[k = 8 lh + j][n = li], j = 0..7: 8 consecutive k, 4 packed registers.)
+    pf_u32x4 bw[G0 + G1]; // bit patterns: 4 f32 (k = 16 g + 4 lh + w) or 8 bf16 (k = 32 g + 8 lh + j)
     {
-        const float *wi = a.Wi[l] + (size_t)(wave * R + u0 + li) * Kin + 4 * lh;
+        auto frag = [&](const float *row, int kw, int g) -> pf_u32x4 {
+            if constexpr (!BF) {
+                pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (16 * g + 4 * lh < kw) v = *reinterpret_cast<const pf_f32x4 *>(row + 16 * g + 4 * lh); // kw % 4 == 0
+                return __builtin_bit_cast(pf_u32x4, v);
+            } else {
+                pf_f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                const int k = 32 * g + 8 * lh;
+                if (k < kw) v0 = *reinterpret_cast<const pf_f32x4 *>(row + k);
+                if (k + 4 < kw) v1 = *reinterpret_cast<const pf_f32x4 *>(row + k + 4);
+                return pf_u32x4{pf_pack_bf16(v0[0], v0[1]), pf_pack_bf16(v0[2], v0[3]), pf_pack_bf16(v1[0], v1[1]), pf_pack_bf16(v1[2], v1[3])};
+            }
+        };
+        const float *wi = a.Wi[l] + (size_t)(wave * R + u0 + li) * Kin;
 #pragma unroll
-        for (int g = 0; g < G0; ++g) {
-            pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (16 * g + 4 * lh < Kin) v = *reinterpret_cast<const pf_f32x4 *>(wi + 16 * g); // Kin % 4 == 0
-            bw[4 * g + 0] = v[0]; bw[4 * g + 1] = v[1]; bw[4 * g + 2] = v[2]; bw[4 * g + 3] = v[3];
-        }
-        const float *wh = a.Wh[l] + (size_t)(wave * R + u0 + li) * R + 4 * lh;
+        for (int g = 0; g < G0; ++g) bw[g] = frag(wi, Kin, g);
+        const float *wh = a.Wh[l] + (size_t)(wave * R + u0 + li) * R;
 #pragma unroll
-        for (int g = 0; g < G1; ++g) {
-            const pf_f32x4 v = *reinterpret_cast<const pf_f32x4 *>(wh + 16 * g);
-            bw[4 * (G0 + g) + 0] = v[0]; bw[4 * (G0 + g) + 1] = v[1]; bw[4 * (G0 + g) + 2] = v[2]; bw[4 * (G0 + g) + 3] = v[3];
-        }
+        for (int g = 0; g < G1; ++g) bw[G0 + g] = frag(wh, R, g);
     }
+    if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 1] = wall_clock64();
     // epilogue ownership: thread -> (row = tid / 4 + 64 e, units u0 + 4 (tid % 4) .. +3), e = 0 .. NE-1
     constexpr int NE = (ROWS + 63) / 64;
     const int eq = tid & 3, erow = tid >> 2;
@@ -149,10 +184,14 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
 
     // ---- buffers that other workgroups write during the launch: sc1 buffer accesses only -----------------------
     const size_t hs_bytes = (size_t)(TS + 1) * B * R * 4, u_bytes = (size_t)TS * B * R * 4;
-    const __amdgpu_buffer_rsrc_t r_in = l == 0 ? pf_rsrc(a.X0, (size_t)TS * B * a.E * 4) : pf_rsrc(a.U[l], u_bytes);
+    const __amdgpu_buffer_rsrc_t r_inf = l == 0 ? pf_rsrc(a.X0, (size_t)TS * B * a.E * 4) : pf_rsrc(a.U[l], u_bytes);
     const __amdgpu_buffer_rsrc_t r_h = pf_rsrc(a.Hs[l], hs_bytes);
     const bool has_next = l + 1 < a.L;
     const __amdgpu_buffer_rsrc_t r_un = has_next ? pf_rsrc(a.U[l + 1], u_bytes) : r_h;
+    const __amdgpu_buffer_rsrc_t r_hb = BF ? pf_rsrc(a.Hb[l], hs_bytes / 2) : r_h;
+    const __amdgpu_buffer_rsrc_t r_unb = BF && has_next ? pf_rsrc(a.Ub[l + 1], u_bytes / 2) : r_h;
+    const __amdgpu_buffer_rsrc_t r_in = INB ? pf_rsrc(a.Ub[l], u_bytes / 2) : r_inf; // what the input chunks load from
+    const __amdgpu_buffer_rsrc_t r_rec = BF ? r_hb : r_h;                             // what the recurrent chunks load from
 
     // staging map of a K chunk: thread -> float4 (row = tid / 16 + 16 j, 16-byte chunk kq = tid % 16)
     const int srow = tid >> 4, skq = tid & 15;
@@ -174,8 +213,14 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     const unsigned grow0 = (unsigned)(rb + RBn * srow); // sorted batch row of this thread's first staged row
     const unsigned toff0 = (grow0 * Kin + 4 * skq) * 4, toff1 = (grow0 * R + 4 * skq) * 4;
     const int jmax = (int)grow0 < B ? (B - (int)grow0 + 16 * RBn - 1) / (16 * RBn) : 0; // rows grow0 + 16 RB j < B  <=>  j < jmax
+    // bf16 source: a 64-deep chunk of a row is 128 bytes = 8 pieces of 16 B: thread -> (row = tid / 8 + 32 j, piece tid % 8),
+    // j < MT / 2 -- half the load instructions, and the piece goes to LDS as it is
+    const int brow = tid >> 3, bkq = tid & 7;
+    const unsigned growb = (unsigned)(rb + RBn * brow);
+    const unsigned step_bytesb = (unsigned)B * R * 2, rstrideb = 32u * RBn * R * 2, toffb = (growb * R + 8 * bkq) * 2;
+    const int jmaxb = (int)growb < B ? (B - (int)growb + 32 * RBn - 1) / (32 * RBn) : 0;
 
-    pf_u32x4 stg[2][MT];
+    pf_u32x4 stg[D][MT];
     unsigned pend = 0; // value of the counter the next flagged chunk depends on, requested a chunk ahead of its use
     // ask for the counter that chunk q of step t waits for (always a load -- of counter 0 when nothing is awaited --
     // so that no load sits under a runtime branch)
@@ -216,39 +261,65 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         // byte offset of this thread's first float4 of the chunk: step base (scalar) + thread part (precomputed) + 256 c;
         // row j of the thread's MT rows is 16 rows further: + j * rstride.  Out-of-range pieces get PF_OOB (| or + keeps
         // them beyond every buffer), 2 vector instructions per load in all.
-        const unsigned sbase = (unsigned)t * (s1 ? step_bytes1 : step_bytes0) + 256u * c;
-        pf_o0 = ((64 * c + 4 * skq < (s1 ? R : Kin)) ? (s1 ? toff1 : toff0) + sbase : PF_OOB) | enm;
+        if constexpr (s1 ? BF : INB) { // bf16 image (K = R, a multiple of 64: no tail)
+            pf_o0 = (toffb + (unsigned)t * step_bytesb + 128u * c) | enm;
+        } else {
+            const unsigned sbase = (unsigned)t * (s1 ? step_bytes1 : step_bytes0) + 256u * c;
+            pf_o0 = ((64 * c + 4 * skq < (s1 ? R : Kin)) ? (s1 ? toff1 : toff0) + sbase : PF_OOB) | enm;
+        }
     };
     // loads j0 .. j1-1 of the chunk prepared by prefetch_begin (one or two per MFMA pair: a burst of MT loads between
     // two groups idles the matrix pipe for the time it takes to issue them)
+    // (pieces are numbered 0 .. MT-1 in both forms; a bf16-image chunk has a load / LDS write on the even ones only)
     auto prefetch_piece = [&](auto q_tag, auto set_tag, auto j0_tag, auto j1_tag) {
         constexpr int q = decltype(q_tag)::value, SET = decltype(set_tag)::value;
         constexpr bool s1 = q >= NC0;
 #pragma unroll
         for (int j = decltype(j0_tag)::value; j < decltype(j1_tag)::value && j < MT; ++j) {
-            const unsigned off = j < jmax ? pf_o0 + (unsigned)j * (s1 ? rstride1 : rstride0) : PF_OOB;
-            stg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_h : r_in, off, 0, 16 /* sc1 */);
+            if constexpr (s1 ? BF : INB) {
+                if (j & 1) continue;
+                const unsigned off = (j >> 1) < jmaxb ? pf_o0 + (unsigned)(j >> 1) * rstrideb : PF_OOB;
+                stg[SET][j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rec : r_in, off, 0, 16 /* sc1 */);
+            } else {
+                const unsigned off = j < jmax ? pf_o0 + (unsigned)j * (s1 ? rstride1 : rstride0) : PF_OOB;
+                stg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rec : r_in, off, 0, 16 /* sc1 */);
+            }
         }
     };
     auto prefetch = [&](int t, auto q_tag, auto set_tag, bool en) {
         prefetch_begin(t, q_tag, en);
         prefetch_piece(q_tag, set_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
     };
-    auto commit_piece = [&](auto set_tag, int stage, auto j0_tag, auto j1_tag) {
-        constexpr int SET = decltype(set_tag)::value;
+    // chunk q (compile time: it decides the form of the staged pieces) -> ring stage
+    auto commit_piece = [&](auto q_tag, auto set_tag, int stage, auto j0_tag, auto j1_tag) {
+        constexpr int q = decltype(q_tag)::value, SET = decltype(set_tag)::value;
+        constexpr bool s1 = q >= NC0;
         float *dst = ring + stage * STAGE;
 #pragma unroll
         for (int j = decltype(j0_tag)::value; j < decltype(j1_tag)::value && j < MT; ++j) {
-            const int row = srow + 16 * j;
-            *reinterpret_cast<pf_u32x4 *>(&dst[row * 64 + 4 * (skq ^ (row & 15))]) = stg[SET][j];
+            if constexpr (s1 ? BF : INB) {
+                if (j & 1) continue;
+                const int row = brow + 32 * (j >> 1);
+                *reinterpret_cast<pf_u32x4 *>(&dst[row * 32 + 4 * (bkq ^ ((row >> 1) & 7))]) = stg[SET][j >> 1];
+            } else {
+                const int row = srow + 16 * j;
+                if constexpr (!BF) {
+                    *reinterpret_cast<pf_u32x4 *>(&dst[row * 64 + 4 * (skq ^ (row & 15))]) = stg[SET][j];
+                } else { // 128-byte rows: the 16-byte chunk index (skq / 2) is XOR-ed with row / 2, this thread's 4 k are half a chunk
+                    const pf_f32x4 v = __builtin_bit_cast(pf_f32x4, stg[SET][j]);
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t h = {pf_pack_bf16(v[0], v[1]), pf_pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<u32x2_t *>(&dst[row * 32 + 4 * ((skq >> 1) ^ ((row >> 1) & 7)) + 2 * (skq & 1)]) = h;
+                }
+            }
         }
     };
-    auto commit = [&](auto set_tag, int stage) {
-        commit_piece(set_tag, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
+    auto commit = [&](auto q_tag, auto set_tag, int stage) {
+        commit_piece(q_tag, set_tag, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
     };
 
     pf_f32x4 acc[MT];
-    pf_f32x4 af[MT]; // A fragments of the group about to be multiplied (carried across chunks and steps)
+    pf_u32x4 af[MT]; // A fragments of the group about to be multiplied (carried across chunks and steps): 4 f32 or 8 bf16
     // MFMAs of group g of chunk q (compile time: they select the resident B fragments).  The A fragments of a
     // row-tile pair are replaced right after the pair's MFMAs -- by the next group of the chunk, or (last group) by
     // the first group of the NEXT chunk from ring stage `nxt` -- so a full group of other pairs' MFMAs hides the LDS
@@ -259,21 +330,33 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         constexpr int q = decltype(q_tag)::value, g = decltype(g_tag)::value;
         constexpr bool s1 = q >= NC0;
         constexpr int c = s1 ? q - NC0 : q;
-        constexpr int GB = s1 ? G0 + 4 * c : 4 * c;                     // first B-fragment group of the chunk
-        constexpr int NG = s1 ? 4 : (4 * c + 4 <= G0 ? 4 : G0 - 4 * c); // groups with data in the chunk
+        constexpr int GB = s1 ? G0 + GPC * c : GPC * c;                                 // first B-fragment group of the chunk
+        constexpr int NG = s1 ? GPC : (GPC * c + GPC <= G0 ? GPC : G0 - GPC * c);       // groups with data in the chunk
         if constexpr (g < NG) {
+            auto frag_at = [&](const float *src, int m, int gi) -> pf_u32x4 {
+                const int row = m * 16 + li;
+                if constexpr (!BF) return *reinterpret_cast<const pf_u32x4 *>(&src[row * 64 + 4 * ((4 * gi + lh) ^ li)]);
+                else return *reinterpret_cast<const pf_u32x4 *>(&src[row * 32 + 4 * ((4 * gi + lh) ^ ((row >> 1) & 7))]);
+            };
             auto pair = [&](auto mp_tag) {
                 constexpr int mp = decltype(mp_tag)::value;
+                if constexpr (!BF) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int m = mp; m < mp + 2 && m < MT; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(pf_f32x4, af[m])[w],
+                                                                          __builtin_bit_cast(pf_f32x4, bw[GB + g])[w], acc[m], 0, 0, 0);
+                } else {
 #pragma unroll
                     for (int m = mp; m < mp + 2 && m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][w], bw[4 * (GB + g) + w], acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, af[m]),
+                                                                         __builtin_bit_cast(pf_bf16x8, bw[GB + g]), acc[m], 0, 0, 0);
+                }
                 const float *src = g + 1 < NG ? cur : nxt;
                 constexpr int gn = g + 1 < NG ? g + 1 : 0;
 #pragma unroll
-                for (int m = mp; m < mp + 2 && m < MT; ++m)
-                    af[m] = *reinterpret_cast<const pf_f32x4 *>(&src[(m * 16 + li) * 64 + 4 * ((4 * gn + lh) ^ li)]);
+                for (int m = mp; m < mp + 2 && m < MT; ++m) af[m] = frag_at(src, m, gn);
                 hook(mp_tag); // a piece of the next chunks' housekeeping, under this pair's MFMAs
                 // keep the refill (and the piece) HERE: left alone, hipcc sinks these reads to just above their first use
                 // (shorter live range) and every pair then opens with an exposed LDS round trip -- 15 % of the step
@@ -286,7 +369,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         constexpr int q = decltype(q_tag)::value;
         constexpr bool s1 = q >= NC0;
         constexpr int c = s1 ? q - NC0 : q;
-        return std::integral_constant<int, (s1 ? 4 : (4 * c + 4 <= G0 ? 4 : G0 - 4 * c))>{};
+        return std::integral_constant<int, (s1 ? GPC : (GPC * c + GPC <= G0 ? GPC : G0 - GPC * c))>{};
     };
 
     // fused cell for step t (active = false: the whole row block has not started / has stopped: zeros), then publish
@@ -364,6 +447,14 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
             if (has_next)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, un), r_un,
                                                        (unsigned)((srow_g * R + u0 + 4 * eq) * 4), 0, 16);
+            if constexpr (BF) { // the images the K chunks read: same values, rounded once here instead of at every reader
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pf_pack_bf16(hn[0], hn[1]), pf_pack_bf16(hn[2], hn[3])}, r_hb,
+                                                      (unsigned)(so * 2), 0, 16);
+                if (has_next)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pf_pack_bf16(un[0], un[1]), pf_pack_bf16(un[2], un[3])}, r_unb,
+                                                          (unsigned)((srow_g * R + u0 + 4 * eq) * 2), 0, 16);
+            }
         }
         if (defer) return; // drained and signalled from the next step's first chunk, under its MFMAs (publish_deferred)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
@@ -376,14 +467,20 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
 
     if (t_lo < t_hi) {
         unsigned n = 0; // running chunk counter: ring stage = n % NST
-        // pipeline prologue: chunks 0 and 1 of the first active step
+        // pipeline prologue: chunks 0 .. D-1 of the first active step (all input chunks: NC0 > D)
         poll_request(t_lo, std::integral_constant<int, 0>{}, true);
         prefetch(t_lo, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, true);
-        commit(std::integral_constant<int, 0>{}, 0);
-        prefetch(t_lo, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, true);
+        commit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            (prefetch(t_lo, std::integral_constant<int, Q + 1>{}, std::integral_constant<int, Q + 1>{}, true), ...);
+        }(std::make_integer_sequence<int, D - 1>{});
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const pf_f32x4 *>(&ring[(m * 16 + li) * 64 + 4 * (lh ^ li)]);
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + li;
+            af[m] = BF ? *reinterpret_cast<const pf_u32x4 *>(&ring[row * 32 + 4 * (lh ^ ((row >> 1) & 7))])
+                       : *reinterpret_cast<const pf_u32x4 *>(&ring[row * 64 + 4 * (lh ^ li)]);
+        }
         // step whose h / Dropout(h) stores are issued but not yet drained and signalled.  (publish() takes it through
         // readfirstlane into 32-bit index arithmetic: as a sign-extended 64-bit vector index, at the 512-register
         // limit this kernel runs at, hipcc 7.2 lost the high half in one build and the add went astray.)
@@ -401,33 +498,34 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
                 //   group 0 | request chunk q+2 | group 1 | chunk q+1 -> LDS | group 2 | barrier | group 3 (+ first
                 //   fragments of chunk q+1).  Chunks with fewer groups keep the order of the remaining pieces.
                 // chunk q+2: flag check + offsets now, its loads two per MFMA pair under group 0
-                if constexpr (q + 2 < NT) prefetch_begin(t, std::integral_constant<int, q + 2>{}, true);
-                else prefetch_begin(more ? t + 1 : t, std::integral_constant<int, q + 2 - NT>{}, more);
-                constexpr int QN = q + 2 < NT ? q + 2 : q + 2 - NT; // index of that chunk inside its step
+                if constexpr (q + D < NT) prefetch_begin(t, std::integral_constant<int, q + D>{}, true);
+                else prefetch_begin(more ? t + 1 : t, std::integral_constant<int, q + D - NT>{}, more);
+                constexpr int QN = q + D < NT ? q + D : q + D - NT; // index of that chunk inside its step
                 auto none = [](auto) {};
                 auto loads = [&](auto mp_tag) {
                     constexpr int mp = decltype(mp_tag)::value;
-                    prefetch_piece(std::integral_constant<int, QN>{}, std::integral_constant<int, q & 1>{},
+                    prefetch_piece(std::integral_constant<int, QN>{}, std::integral_constant<int, q % D>{},
                                    std::integral_constant<int, mp>{}, std::integral_constant<int, mp + 2>{});
                 };
                 auto writes = [&](auto mp_tag) { // chunk q+1 -> LDS (a chunk that does not exist arrives as zeros, never multiplied)
                     constexpr int mp = decltype(mp_tag)::value;
-                    commit_piece(std::integral_constant<int, (q + 1) & 1>{}, (int)((n + 1) % NST), std::integral_constant<int, mp>{},
-                                 std::integral_constant<int, mp + 2>{});
+                    commit_piece(std::integral_constant<int, (q + 1) % NT>{}, std::integral_constant<int, (q + 1) % D>{}, (int)((n + 1) % NST),
+                                 std::integral_constant<int, mp>{}, std::integral_constant<int, mp + 2>{});
                 };
                 if constexpr (NG > 1) mfma_group(q_tag, std::integral_constant<int, 0>{}, cur, nxt, loads);
-                else prefetch_piece(std::integral_constant<int, QN>{}, std::integral_constant<int, q & 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
+                else prefetch_piece(std::integral_constant<int, QN>{}, std::integral_constant<int, q % D>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, MT>{});
                 // counter of the flagged chunk that is requested NEXT iteration (chunk q+3), one chunk ahead of its use
-                if constexpr (q + 3 == NC0) poll_request(t, std::integral_constant<int, NC0>{}, true);
-                if constexpr (q + 3 == NT) poll_request(more ? t + 1 : t, std::integral_constant<int, 0>{}, more);
+                if constexpr (q + D + 1 == NC0) poll_request(t, std::integral_constant<int, NC0>{}, true);
+                if constexpr (q + D + 1 == NT) poll_request(more ? t + 1 : t, std::integral_constant<int, 0>{}, more);
                 if constexpr (NG > 2) mfma_group(q_tag, std::integral_constant<int, 1>{}, cur, nxt, writes);
-                else commit(std::integral_constant<int, (q + 1) & 1>{}, (int)((n + 1) % NST));
+                else commit(std::integral_constant<int, (q + 1) % NT>{}, std::integral_constant<int, (q + 1) % D>{}, (int)((n + 1) % NST));
                 if constexpr (NG > 3) mfma_group(q_tag, std::integral_constant<int, 2>{}, cur, nxt, none);
                 if constexpr (q == 0) {
                     // the previous step's write-through stores are older than the MT loads of the prefetch above: drained
                     // here, signalled behind this chunk's barrier (publish R1: every storing wave drains, barrier, one lane)
-                    if (pub >= 0) {
-                        if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    if (pub >= 0) { // (chunk D is an input chunk: MT loads, MT / 2 from a bf16 image)
+                        if constexpr ((INB ? MT / 2 : MT) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else if constexpr ((INB ? MT / 2 : MT) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     }
                 }
@@ -449,17 +547,26 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     for (int t = t_hi; t < TS; ++t) epilogue(t, false, false);
 }
 
-// G0A: K groups of layer 0's input (ceil(E / 16)); GR = R / 16.  Workgroup id -> (layer, row block, unit tile): the
-// NU unit tiles of one (layer, row block) share an id modulo the group count, i.e. one XCD when there are 8 groups.
-template <int G0A, int GR, int MT>
+// KA: K of layer 0's input (E, rounded up to the group width); workgroup id -> (layer, row block, unit tile): the NU unit
+// tiles of one (layer, row block) share an id modulo the group count, i.e. one XCD when there are 8 groups.
+template <int KA, int KR, int MT, bool BF>
 __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_fwd_persist(PersistFwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float pf_smem[];
+    constexpr int KG = BF ? 32 : 16, G0A = (KA + KG - 1) / KG, GR = KR / KG;
     const int groups = a.L * a.RB;
     const int grp = blockIdx.x % groups, ut = blockIdx.x / groups;
     const int l = grp / a.RB, rb = grp % a.RB;
-    if (l == 0) persist_fwd_layer<G0A, GR, MT>(a, l, rb, ut, pf_smem);
-    else persist_fwd_layer<GR, GR, MT>(a, l, rb, ut, pf_smem);
+    if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4] = wall_clock64();
+    if (l == 0) persist_fwd_layer<G0A, GR, MT, BF, false>(a, l, rb, ut, pf_smem);
+    else persist_fwd_layer<GR, GR, MT, BF, BF>(a, l, rb, ut, pf_smem);
+    if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
+}
+template <int KA, int KR, int MT, bool BF> constexpr size_t persist_fwd_lds()
+{
+    constexpr int KG = BF ? 32 : 16, G0A = (KA + KG - 1) / KG, GR = KR / KG;
+    return PersistGeom<G0A, GR, MT, BF>::LDS_BYTES > PersistGeom<GR, GR, MT, BF>::LDS_BYTES ? PersistGeom<G0A, GR, MT, BF>::LDS_BYTES
+                                                                                          : PersistGeom<GR, GR, MT, BF>::LDS_BYTES;
 }
 
 } // namespace nvqa

@@ -18,6 +18,13 @@
 // loads and read the bytes with sc1 buffer loads):  REC(l, s) waits for REC(l, s+1) [its A operand, all unit tiles
 // of the row block] and, below the top layer, for the one UP(l, s) tile with its rows and units; UP(l, s) waits for
 // REC(l+1, s).  No cycle: the top layer waits only for itself.  Every spin is bounded (err word).
+//
+// bf16 instance (nvqa_set_precision(1)): v_mfma_f32_16x16x32_bf16, the weights as packed bf16 (half the registers), so a
+// workgroup holds 64 units (4 column tiles per wave) instead of 32 and HALF as many workgroups re-read each dG slice;
+// the A operand comes from a bf16 image of dG that the cell backward writes next to the f32 one (half the bytes again);
+// the LDS image of a chunk is byte-for-byte the f32 layout (4 gates x 32 k x 2 B = 4 x 16 x 4 B per row) and a 16-byte
+// piece IS the lane's A fragment; 4 chunks in flight instead of 2 (a chunk is 0.1 us of MFMAs here, the step is a chain
+// of L2 round trips).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,32 +39,37 @@ struct PersistBwdArgs {
     const float *Cs[NVQA_PF_MAXL];                    // [(TS+1)*B][R]
     const float *dCT, *dHT;                           // [L][B][R] head -> final cell / hidden state gradients
     float *Pup[NVQA_PF_MAXL];                         // Pup[l], l < L-1: [TS*B][R] products of the UP(l) role
+    unsigned short *Gb[NVQA_PF_MAXL];                 // bf16 instance: [TS*B][4R] bf16 image of dG (written by REC, read as A)
     const int *nrows, *sort_idx, *tlast;              // tlast (arch2): dHT enters at step *tlast; NULL (arch1): at TS-1
     unsigned *cnt_rec;                                // [L][RB][TS] arrivals of the REC(l) unit tiles
     unsigned *cnt_up;                                 // [L][RB][NU][TS] flag of the UP(l) tile
     unsigned *err;
     unsigned spin_limit;
+    unsigned long long *ts;  // dbg & 32: per workgroup {start, weights resident, steps done} in 100 MHz ticks
     int dbg;                 // measurement only (NVQA_PB_DBG): 1 no flag waits, 2 no cell math / stores, 8 A loads without memory traffic
-    int B, R, L, TS, RB, NU; // NU = R / 32 unit tiles
+    int B, R, L, TS, RB, NU; // NU = R / (16 NTN) unit tiles
     Drop dr;
 };
 
-template <int GK, int MT> struct PersistBwdGeom {
-    static constexpr int ROWS = 16 * MT, NST = 3, STAGE = ROWS * 64;
-    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWS * 32) * 4; // ring + the four waves' partial tiles
+template <int MT, int NTN> struct PersistBwdGeom {
+    static constexpr int ROWS = 16 * MT, NST = 3, STAGE = ROWS * 64, UNITS = 16 * NTN;
+    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWS * UNITS) * 4; // ring + the four waves' partial tiles
 };
 
-// GK = R / 16: 16-wide K groups per gate; MT row tiles of 16 rows per workgroup
-template <int GK, int MT>
+// GK: K groups (= chunks) per gate: R / 16 (f32), R / 32 (bf16); MT row tiles of 16 rows and NTN column tiles of 16 units
+// per workgroup
+template <int GK, int MT, int NTN, bool BF>
 __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(PersistBwdArgs a)
 {
-    typedef PersistBwdGeom<GK, MT> GE;
-    static_assert(GK % 2 == 0, "chunks per step must be even (static staging-register sets)");
+    typedef PersistBwdGeom<MT, NTN> GE;
+    constexpr int D = BF ? 4 : 2; // chunks in flight = staging-register sets
+    static_assert(GK % D == 0, "chunks per step must be a multiple of the prefetch distance (static staging-register sets)");
     static_assert(MT >= 3, "at least two row-tile pairs: one before the chunk barrier, one after");
-    constexpr int ROWS = GE::ROWS, NST = GE::NST, STAGE = GE::STAGE, NT = GK;
+    constexpr int ROWS = GE::ROWS, NST = GE::NST, STAGE = GE::STAGE, NT = GK, UNITS = GE::UNITS;
+    constexpr int ES = BF ? 2 : 4, KG = BF ? 32 : 16; // bytes per A element, K per group
     extern __shared__ __attribute__((aligned(16))) float pb_smem[];
-    float *const ring = pb_smem;               // [NST][ROWS][64]: per row 4 gates x 16 k, 16-byte chunks XOR-swizzled
-    float *const Sred = pb_smem + NST * STAGE; // [4 waves][ROWS][32] partial tiles
+    float *const ring = pb_smem;               // [NST][ROWS][64 words]: per row 4 gates x 16 B x 4, 16-byte pieces XOR-swizzled
+    float *const Sred = pb_smem + NST * STAGE; // [4 waves][ROWS][UNITS] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS, L = a.L, RBn = a.RB;
 
@@ -77,33 +89,41 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
     const bool is_up = role >= L;
     const int l = is_up ? 2 * L - 2 - role : L - 1 - role; // the layer whose dh this tile belongs to
     const int la = is_up ? l + 1 : l;                      // the layer whose dG is the A operand
-    const int u0 = ut * 32;
+    const int u0 = ut * UNITS;
     const bool has_up = !is_up && l + 1 < L;               // REC below the top layer: adds the UP(l) tile
+    if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4] = wall_clock64();
 
     // ---- weights: rows k = wave * R + kk (gate `wave`), columns u0 .. u0+31 of W [4R][R]; resident B fragments ---------
     const float *W = is_up ? a.Wi[l + 1] : a.Wh[l];
-    float bw[2][GK * 4];
+    pf_u32x4 bw[NTN][GK]; // f32: 4 k = 16 g + 4 lh + w; bf16: 8 k = 32 g + 8 lh + j (packed pairs)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-        for (int g = 0; g < GK; ++g)
+        for (int g = 0; g < GK; ++g) {
+            const float *w0 = W + (size_t)(wave * R + KG * g + (KG / 4) * lh) * R + u0 + 16 * nt + li;
+            if constexpr (!BF) {
+                bw[nt][g] = __builtin_bit_cast(pf_u32x4, pf_f32x4{w0[0], w0[(size_t)R], w0[2 * (size_t)R], w0[3 * (size_t)R]});
+            } else {
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                bw[nt][4 * g + w] = W[(size_t)(wave * R + 16 * g + 4 * lh + w) * R + u0 + 16 * nt + li];
+                for (int j = 0; j < 4; ++j) bw[nt][g][j] = pf_pack_bf16(w0[(size_t)(2 * j) * R], w0[(size_t)(2 * j + 1) * R]);
+            }
+        }
 
+    if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 1] = wall_clock64();
     const size_t gt_bytes = (size_t)TS * B * 4 * R * 4, pup_bytes = (size_t)TS * B * R * 4;
-    const __amdgpu_buffer_rsrc_t r_a = pf_rsrc(a.Gt[la], gt_bytes);                  // A operand: dG of layer la
+    const __amdgpu_buffer_rsrc_t r_a = BF ? pf_rsrc(a.Gb[la], gt_bytes / 2) : pf_rsrc(a.Gt[la], gt_bytes); // A operand: dG of layer la
+    const __amdgpu_buffer_rsrc_t r_gb = BF ? pf_rsrc(a.Gb[l], gt_bytes / 2) : r_a;   // REC, bf16: the image of dG it writes
     const __amdgpu_buffer_rsrc_t r_g = pf_rsrc(a.Gt[l], gt_bytes);                   // REC: gates in / dG out
     const __amdgpu_buffer_rsrc_t r_p = pf_rsrc(l + 1 < L ? a.Pup[l] : a.Gt[l], l + 1 < L ? pup_bytes : gt_bytes);
 
     // staging map of a chunk (K group g): thread -> (row = tid / 16 + 16 j, piece kq = tid % 16 = gate kq / 4, 4 (kq % 4) .. +3)
     const int srow = tid >> 4, skq = tid & 15;
     const unsigned grow0 = (unsigned)(rb + RBn * srow);
-    const unsigned toff = (grow0 * 4u * R + (unsigned)(skq >> 2) * R + 4u * (skq & 3)) * 4u;
-    const unsigned rstride = 16u * RBn * 4u * R * 4u, step_bytes = (unsigned)B * 4u * R * 4u;
+    const unsigned toff = (grow0 * 4u * R + (unsigned)(skq >> 2) * R + (16u / ES) * (skq & 3)) * ES;
+    const unsigned rstride = 16u * RBn * 4u * R * ES, step_bytes = (unsigned)B * 4u * R * ES;
     const int jmax = (int)grow0 < B ? (B - (int)grow0 + 16 * RBn - 1) / (16 * RBn) : 0;
 
-    pf_u32x4 stg[2][MT];
+    pf_u32x4 stg[D][MT];
     unsigned pf_o0 = PF_OOB;
     // A slice `sa` of Gt[la] (dG of step sa), K group g; en = false: zeros without memory traffic
     auto prefetch_begin = [&](int sa, auto g_tag, bool en) {
@@ -131,32 +151,42 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
     const auto J0 = std::integral_constant<int, 0>{};
     const auto JN = std::integral_constant<int, MT>{};
 
-    pf_f32x4 acc[MT][2];
-    pf_f32x4 af[MT];
+    pf_f32x4 acc[MT][NTN];
+    pf_u32x4 af[MT];
     auto refill = [&](const float *src, auto m0_tag, auto m1_tag) { // this wave's 4 k of every row tile: piece 4 wave + lh
 #pragma unroll
         for (int m = decltype(m0_tag)::value; m < decltype(m1_tag)::value && m < MT; ++m)
-            af[m] = *reinterpret_cast<const pf_f32x4 *>(&src[(m * 16 + li) * 64 + 4 * ((4 * wave + lh) ^ li)]);
+            af[m] = *reinterpret_cast<const pf_u32x4 *>(&src[(m * 16 + li) * 64 + 4 * ((4 * wave + lh) ^ li)]);
     };
-    // MFMAs of row tiles mp, mp+1 for K group g (2 x 2 x 4: an accumulator is reused every 4th MFMA)
+    // MFMAs of row tiles mp, mp+1 for K group g (f32: 2 x NTN x 4, an accumulator is reused every 2 NTN-th MFMA)
     auto pair = [&](auto g_tag, auto mp_tag) {
         constexpr int g = decltype(g_tag)::value, mp = decltype(mp_tag)::value;
+        if constexpr (!BF) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int m = mp; m < mp + 2 && m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(pf_f32x4, af[m])[w],
+                                                                          __builtin_bit_cast(pf_f32x4, bw[nt][g])[w], acc[m][nt], 0, 0, 0);
+        } else {
 #pragma unroll
             for (int m = mp; m < mp + 2 && m < MT; ++m)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][w], bw[nt][4 * g + w], acc[m][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTN; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, af[m]),
+                                                                         __builtin_bit_cast(pf_bf16x8, bw[nt][g]), acc[m][nt], 0, 0, 0);
+        }
     };
 
-    // epilogue ownership: thread -> (row = tid / 8 + 32 e, units u0 + 4 (tid % 8) .. +3)
-    constexpr int NE = (ROWS + 31) / 32;
-    const int eq = tid & 7, erow = tid >> 3;
+    // epilogue ownership: thread -> (row = tid / QPR + RPP e, units u0 + 4 (tid % QPR) .. +3), QPR = quads per row
+    constexpr int QPR = UNITS / 4, RPP = NVQA_PF_THREADS / QPR, NE = (ROWS + RPP - 1) / RPP;
+    const int eq = tid % QPR, erow = tid / QPR;
     float dcst[NE][4]; // REC: the carried cell gradient of the owned (row, unit)s
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        const int row = erow + 32 * e, grow = rb + RBn * row;
+        const int row = erow + RPP * e, grow = rb + RBn * row;
         pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!is_up && row < ROWS && grow < B) v = *reinterpret_cast<const pf_f32x4 *>(a.dCT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
 #pragma unroll
@@ -167,6 +197,32 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
     const unsigned cup = (unsigned)(((l * RBn + rb) * a.NU + ut) * TS);    // UP(l) flag of this tile
 
     for (int s = TS - 1; s >= 0; --s) {
+        // REC: the cell backward's operands (own gates and cell states of the forward pass: nothing in this launch writes
+        // them before this workgroup does) are requested HERE, ahead of the counter wait and the whole product, for the
+        // first two of the thread's NE items -- as many as fit beside the resident weights; the other items are requested
+        // as the first two are consumed.  Requested in the epilogue they were 4 exposed HBM round trips per step (4.4 us).
+        const int nr = a.nrows[s];
+        const bool head_now = a.tlast ? (*a.tlast == s) : (s == TS - 1);
+        pf_f32x4 e_ig[2], e_fg[2], e_og[2], e_gg[2], e_cc[2], e_cp[2];
+        int e_si[2];
+        pf_f32x4 e_v2[NE]; // the UP(l, s) products of the owned cells (another workgroup's bytes: after its flag, sc1 loads)
+        auto fetch = [&](int e, int k) { // unconditional, row clamped into the batch
+            if (a.dbg & 4) return; // measurement: the cell backward's operands are not loaded
+            const int row = erow + RPP * e, grow = min(rb + RBn * row, B - 1);
+            const size_t srow_g = (size_t)s * B + grow;
+            const float *gt = a.Gt[l] + srow_g * 4 * R + u0 + 4 * eq; // own gates of the forward pass: plain loads
+            e_ig[k] = *reinterpret_cast<const pf_f32x4 *>(gt);
+            e_fg[k] = *reinterpret_cast<const pf_f32x4 *>(gt + R);
+            e_og[k] = *reinterpret_cast<const pf_f32x4 *>(gt + 2 * R);
+            e_gg[k] = *reinterpret_cast<const pf_f32x4 *>(gt + 3 * R);
+            e_cc[k] = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + ((size_t)(s + 1) * B + grow) * R + u0 + 4 * eq);
+            e_cp[k] = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + srow_g * R + u0 + 4 * eq);
+            e_si[k] = a.sort_idx[grow];
+        };
+        if (!is_up) {
+            fetch(0, 0);
+            if constexpr (NE > 1) fetch(1, 1);
+        }
         // A operand: REC(l, s): dG^l_{s+1} (absent at the last step); UP(l, s): dG^{l+1}_s
         const int sa = is_up ? s : s + 1;
         const bool live = sa < TS && !(a.dbg & 8);
@@ -175,13 +231,19 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             (void)pf_wait_ge(a.cnt_rec + cneed + sa, (unsigned)a.NU, a.err, (is_up ? 0x400u : 0x300u) + l, a.spin_limit);
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { acc[m][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = acc[m][0]; }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) acc[m][nt] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         // pipeline prologue (nothing can be requested before the producers' step is complete: the chain is serial here)
         prefetch_begin(sa, std::integral_constant<int, 0>{}, live);
         prefetch_piece(std::integral_constant<int, 0>{}, J0, JN);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { // chunks 1 .. D-1
+            ([&] {
+                prefetch_begin(sa, std::integral_constant<int, Q + 1>{}, live);
+                prefetch_piece(std::integral_constant<int, Q + 1>{}, J0, JN);
+            }(), ...);
+        }(std::make_integer_sequence<int, D - 1>{});
         commit_piece(std::integral_constant<int, 0>{}, 0, J0, JN);
-        prefetch_begin(sa, std::integral_constant<int, 1>{}, live);
-        prefetch_piece(std::integral_constant<int, 1>{}, J0, JN);
         __syncthreads();
         refill(ring, J0, JN);
         auto iter = [&](auto q_tag) {
@@ -189,17 +251,17 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             const float *nxt = ring + ((q + 1) % NST) * STAGE;
             // pairs 0 .. NP-2 before the barrier with the next chunks' housekeeping under them, the last pair after it
             constexpr int NP = (MT + 1) / 2;
-            if constexpr (q + 2 < NT) prefetch_begin(sa, std::integral_constant<int, (q + 2 < NT ? q + 2 : 0)>{}, live);
+            if constexpr (q + D < NT) prefetch_begin(sa, std::integral_constant<int, (q + D < NT ? q + D : 0)>{}, live);
             [&]<int... P>(std::integer_sequence<int, P...>) {
                 ([&] {
                     pair(q_tag, std::integral_constant<int, 2 * P>{});
-                    if constexpr (q + 2 < NT) // loads of chunk q+2: spread over the pairs before the barrier
-                        prefetch_piece(std::integral_constant<int, q & 1>{}, std::integral_constant<int, (MT * P) / (NP - 1)>{},
+                    if constexpr (q + D < NT) // loads of chunk q+D: spread over the pairs before the barrier
+                        prefetch_piece(std::integral_constant<int, q % D>{}, std::integral_constant<int, (MT * P) / (NP - 1)>{},
                                        std::integral_constant<int, (MT * (P + 1)) / (NP - 1)>{});
                     // chunk q+1 -> LDS (its loads were issued a chunk ago), one pair ahead of the barrier where there is one:
                     // the writes then land under that pair's MFMAs instead of in front of the barrier
                     if constexpr (q + 1 < NT && P == (NP >= 3 ? NP - 3 : NP - 2))
-                        commit_piece(std::integral_constant<int, (q + 1) & 1>{}, (q + 1) % NST, J0, JN);
+                        commit_piece(std::integral_constant<int, (q + 1) % D>{}, (q + 1) % NST, J0, JN);
                     __builtin_amdgcn_sched_barrier(0);
                 }(), ...);
             }(std::make_integer_sequence<int, NP - 1>{});
@@ -217,36 +279,15 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Sred[(wave * ROWS + 16 * m + 4 * lh + r) * 32 + 16 * nt + li] = acc[m][nt][r];
-        // REC: what the cell backward needs besides the product is requested before the barrier, under the partial sums'
-        // LDS traffic
-        const int nr = a.nrows[s];
-        const bool head_now = a.tlast ? (*a.tlast == s) : (s == TS - 1);
-        // one item ahead: all four at once do not fit beside the 256 resident weight registers
-        pf_f32x4 e_ig[2], e_fg[2], e_og[2], e_gg[2], e_cc[2], e_cp[2], e_v2[2];
-        int e_si[2];
-        auto fetch = [&](int e, int k) { // unconditional, row clamped into the batch
-            const int row = erow + 32 * e, grow = min(rb + RBn * row, B - 1);
-            const size_t srow_g = (size_t)s * B + grow;
-            const float *gt = a.Gt[l] + srow_g * 4 * R + u0 + 4 * eq; // own gates of the forward pass: plain loads
-            e_ig[k] = *reinterpret_cast<const pf_f32x4 *>(gt);
-            e_fg[k] = *reinterpret_cast<const pf_f32x4 *>(gt + R);
-            e_og[k] = *reinterpret_cast<const pf_f32x4 *>(gt + 2 * R);
-            e_gg[k] = *reinterpret_cast<const pf_f32x4 *>(gt + 3 * R);
-            e_cc[k] = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + ((size_t)(s + 1) * B + grow) * R + u0 + 4 * eq);
-            e_cp[k] = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + srow_g * R + u0 + 4 * eq);
-            e_v2[k] = __builtin_bit_cast(pf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       r_p, has_up ? (unsigned)((srow_g * R + u0 + 4 * eq) * 4) : PF_OOB, 0, 16));
-            e_si[k] = a.sort_idx[grow];
-        };
+                for (int r = 0; r < 4; ++r) Sred[(wave * ROWS + 16 * m + 4 * lh + r) * UNITS + 16 * nt + li] = acc[m][nt][r];
         auto finish = [&](int e, int k) {
-            const int row = erow + 32 * e, grow = rb + RBn * row;
+            const int row = erow + RPP * e, grow = rb + RBn * row;
             if (row >= ROWS || grow >= B || (a.dbg & 2)) return;
             pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&Sred[(w * ROWS + row) * 32 + 4 * eq]);
+            for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&Sred[(w * ROWS + row) * UNITS + 4 * eq]);
             const size_t srow_g = (size_t)s * B + grow;
             const unsigned uo = (unsigned)((srow_g * R + u0 + 4 * eq) * 4);
             if (is_up) { // ship the product; the cell of layer l adds it
@@ -256,7 +297,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             const unsigned go = (unsigned)((srow_g * 4 * R + u0 + 4 * eq) * 4);
             pf_f32x4 dgi = {0.f, 0.f, 0.f, 0.f}, dgf = dgi, dgo = dgi, dgg = dgi, dcn = dgi;
             if (grow < nr) {
-                const pf_f32x4 ig = e_ig[k], fg = e_fg[k], og = e_og[k], gg = e_gg[k], cc = e_cc[k], cp = e_cp[k], v2 = e_v2[k];
+                const pf_f32x4 ig = e_ig[k], fg = e_fg[k], og = e_og[k], gg = e_gg[k], cc = e_cc[k], cp = e_cp[k], v2 = e_v2[e];
                 pf_f32x4 hx = {0.f, 0.f, 0.f, 0.f};
                 if (head_now) hx = *reinterpret_cast<const pf_f32x4 *>(a.dHT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
                 const uint64_t didx = ((((uint64_t)l) * B + e_si[k]) * TS + s) * R + u0 + 4 * eq;
@@ -279,17 +320,30 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgf), r_g, go + (unsigned)R * 4, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgo), r_g, go + 2u * R * 4, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgg), r_g, go + 3u * R * 4, 0, 16);
+            if constexpr (BF) { // the image the REC / UP products read (the f32 one stays what the weight gradients read)
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                auto img = [&](const pf_f32x4 &x, unsigned gate) {
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pf_pack_bf16(x[0], x[1]), pf_pack_bf16(x[2], x[3])}, r_gb,
+                                                          go / 2 + gate * (unsigned)R * 2, 0, 16);
+                };
+                img(dgi, 0); img(dgf, 1); img(dgo, 2); img(dgg, 3);
+            }
         };
         if (!is_up) {
             if (has_up && !(a.dbg & 1)) // the UP(l, s) tile with these rows and units (normally long since there: UP runs ahead)
                 (void)pf_wait_ge(a.cnt_up + cup + s, 1u, a.err, 0x500u + l, a.spin_limit);
-            fetch(0, 0);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int row = erow + RPP * e, grow = min(rb + RBn * row, B - 1);
+                e_v2[e] = __builtin_bit_cast(pf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           r_p, has_up ? (unsigned)((((size_t)s * B + grow) * R + u0 + 4 * eq) * 4) : PF_OOB, 0, 16));
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < NE; ++e) { // the next item's loads are in flight while this one is computed
-            if (!is_up && e + 1 < NE) fetch(e + 1, (e + 1) & 1);
+        for (int e = 0; e < NE; ++e) {
             finish(e, e & 1); // dcst is indexed by the compile-time e after unrolling
+            if (!is_up && e + 2 < NE) fetch(e + 2, e & 1); // the slot just consumed takes the item after next
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
         __syncthreads();                                 // (also: Sred and the ring are free for the next step)
@@ -299,6 +353,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
 }
 
 } // namespace nvqa

@@ -319,6 +319,8 @@ static int create_impl(nvqa_ctx *c)
         c->num_cus = prop.multiProcessorCount;
         c->pf_cnt_words = ((size_t)L * ((B + 63) / 64) * TS + 4 + 3) / 4 * 4; // counters for the finest row blocking + err word, 16-byte multiple
         NVQA_TRY(dalloc(&c->pf_cnt, c->pf_cnt_words));
+        NVQA_TRY(dalloc(&c->pf_ts, 2048)); // NVQA_PF_DBG / NVQA_PB_DBG & 32: timestamps of 256 + 256 workgroups
+        NVQA_HIP(hipMemsetAsync(c->pf_ts, 0, 2048 * 8, c->s));
         NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 8 * sizeof(unsigned), hipHostMallocDefault));
         memset(c->h_pf_err, 0, 32);
         // persistent BPTT (lstm_persist_bwd.h): opt-in with NVQA_PERSIST_BWD=1 -- parity-green, but at 46 us per step it
@@ -326,7 +328,7 @@ static int create_impl(nvqa_ctx *c)
         // 2 us, K-quarter reduction + cell backward + write-through drain 9 us) cannot hide behind an independent K
         // segment the way the forward kernel's does
         const char *eb = getenv("NVQA_PERSIST_BWD");
-        c->persist_bwd_on = eb && eb[0] == '1';
+        c->persist_bwd_on = !eb ? -1 : (eb[0] == '1' ? 1 : 0); // unset: on for the bf16 instance only (persist_bwd_rows)
         if (d.R == 512 && L <= 2) {
             const size_t rbmax = (B + 63) / 64;
             c->pb_cnt_words = (L * rbmax * TS * (1 + R / 32) + 4 + 3) / 4 * 4;
@@ -362,6 +364,9 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->h_loss) (void)hipHostFree(c->h_loss);
     if (c->h_pf_err) (void)hipHostFree(c->h_pf_err);
     if (c->pf_cnt) (void)hipFree(c->pf_cnt);
+    if (c->pf_ts) (void)hipFree(c->pf_ts);
+    if (c->act_b16) (void)hipFree(c->act_b16);
+    if (c->dg_b16) (void)hipFree(c->dg_b16);
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
     for (hipEvent_t e : {c->evComm, c->evStart})
@@ -377,11 +382,30 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
 // after the stream has drained: did a persistent-kernel wait give up? (lstm_persist.h: every spin is bounded)
 static int check_persist(nvqa_ctx *c)
 {
+    static const int ts_dbg = [] { const char *a = getenv("NVQA_PF_DBG"), *b = getenv("NVQA_PB_DBG"); return ((a ? atoi(a) : 0) | (b ? atoi(b) : 0)) & 32; }();
+    if (ts_dbg && c->pf_ts) { // measurement only: phase times of the persistent kernels' workgroups (min / max over workgroups), once
+        static int left = 3;
+        if (left > 0 && --left == 0) {
+            std::vector<unsigned long long> h(2048);
+            if (hipMemcpy(h.data(), c->pf_ts, 2048 * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                for (int k = 0; k < 2; ++k) {
+                    unsigned long long t0 = ~0ull, w_lo = ~0ull, w_hi = 0, e_lo = ~0ull, e_hi = 0; int n = 0;
+                    for (int b = 0; b < 256; ++b) { const unsigned long long *t = &h[k * 1024 + b * 4]; if (t[2]) { t0 = std::min(t0, t[0]); ++n; } }
+                    for (int b = 0; b < 256; ++b) {
+                        const unsigned long long *t = &h[k * 1024 + b * 4];
+                        if (!t[2]) continue;
+                        w_lo = std::min(w_lo, t[1] - t0); w_hi = std::max(w_hi, t[1] - t0); e_lo = std::min(e_lo, t[2] - t0); e_hi = std::max(e_hi, t[2] - t0);
+                    }
+                    if (n) fprintf(stderr, "[nvqa] persistent %s: %d workgroups; weights resident after %.1f .. %.1f us, done after %.1f .. %.1f us\n",
+                                   k ? "BPTT" : "forward", n, w_lo * 0.01, w_hi * 0.01, e_lo * 0.01, e_hi * 0.01);
+                }
+        }
+    }
     if (c->h_pf_err && c->h_pf_err[4]) {
         set_error("persistent BPTT kernel: workgroup %u timed out waiting (code 0x%x, value seen %u); results of that step are invalid",
                   c->h_pf_err[7], c->h_pf_err[4], c->h_pf_err[6]);
         memset(c->h_pf_err + 4, 0, 16);
-        c->persist_bwd_on = false; // later steps take the per-level path
+        c->persist_bwd_on = 0; // later steps take the per-level path
         return -3;
     }
     if (c->h_pf_err && *c->h_pf_err) {
@@ -558,22 +582,22 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
 // ------------------------------------------------------------------------------------
 // The whole forward unroll as one persistent, weight-stationary launch (lstm_persist.h).  Eligible shapes: the two the
 // reference trains (R = 512 with E = 200 [arch1] or E = 512 [arch2]) on a device with one CU per workgroup.
-template <int G0A, int GR, int MT>
+template <int KA, int KR, int MT, bool BF>
 static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 {
-    const size_t lds = std::max(PersistGeom<G0A, GR, MT>::LDS_BYTES, PersistGeom<GR, GR, MT>::LDS_BYTES);
+    const size_t lds = persist_fwd_lds<KA, KR, MT, BF>();
     static int resident = -1; // per instantiation: workgroups of this kernel one CU can hold
     if (resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<G0A, GR, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<KA, KR, MT, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<G0A, GR, MT>, NVQA_PF_THREADS, lds));
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<KA, KR, MT, BF>, NVQA_PF_THREADS, lds));
         resident = nb;
     }
     if (resident < 1 || grid > c->num_cus) { // the workgroups wait for each other: all of them must be resident at once
         set_error("persistent LSTM kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
         return -1;
     }
-    hipLaunchKernelGGL((k_lstm_fwd_persist<G0A, GR, MT>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    hipLaunchKernelGGL((k_lstm_fwd_persist<KA, KR, MT, BF>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -581,7 +605,7 @@ static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 static int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT), or 0 when the path does not apply
 {
     const nvqa_dims &d = c->d;
-    if (!c->persist_on || c->bf16 || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
+    if (!c->persist_on || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
     // every row must be active whenever any row is: arch2 always (all rows run to tmax), arch1 when the host knows that
     // all questions of the batch have one length; ragged arch1 batches take the per-level kernels
     if (d.arch == NVQA_ARCH1 && !c->batch_uniform) return 0;
@@ -593,11 +617,27 @@ static int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT)
     return 0;
 }
 
+// step-0 slices of the bf16 images of Hs (zeros, or the carried h0 of NVQA_QUIRK_H0): layer = blockIdx.y
+__global__ void k_h0_image(const float *Hs, unsigned short *Hb, size_t layer_stride, int n)
+{
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float2 v = *reinterpret_cast<const float2 *>(Hs + blockIdx.y * layer_stride + i);
+    *reinterpret_cast<unsigned *>(Hb + blockIdx.y * layer_stride + i) = pf_pack_bf16(v.x, v.y);
+}
+
 static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS;
     PersistFwdArgs a = {};
+    if (c->bf16) { // bf16 images of Hs and U, [L][(TS+1)*B][R] + [L][TS*B][R] (first use of the bf16 instance)
+        const size_t hs = (size_t)(TS + 1) * B * R, us = (size_t)TS * B * R;
+        if (!c->act_b16) NVQA_HIP(hipMalloc((void **)&c->act_b16, (size_t)L * (hs + us) * 2));
+        for (int l = 0; l < L; ++l) { a.Hb[l] = c->act_b16 + l * hs; a.Ub[l] = c->act_b16 + L * hs + l * us; }
+        hipLaunchKernelGGL(k_h0_image, dim3((B * R / 2 + 255) / 256, L), dim3(256), 0, c->s, c->Hs[0], a.Hb[0], hs, B * R);
+        NVQA_HIP(hipGetLastError());
+    }
     for (int l = 0; l < L; ++l) {
         a.Wi[l] = c->P + c->lo.w_i2h[l]; a.Wh[l] = c->P + c->lo.w_h2h[l];
         a.bi[l] = c->P + c->lo.b_i2h[l]; a.bh[l] = c->P + c->lo.b_h2h[l];
@@ -611,18 +651,21 @@ static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     { static const int dbg = [] { const char *e = getenv("NVQA_PF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
     a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
+    a.ts = c->pf_ts;
     const int grid = L * a.RB * a.NU;
     double flops = 0;
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);
     ProfScope ps(c, PF_LSTM_FWD, flops, 0);
     NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s));
-    if (d.E == 200) {
-        if (MT == 4) NVQA_TRY((launch_persist_fwd<13, 32, 4>(c, a, grid)));
-        else NVQA_TRY((launch_persist_fwd<13, 32, 8>(c, a, grid)));
+#define NVQA_PF_GO(KA, MTv, BFv) NVQA_TRY((launch_persist_fwd<KA, 512, MTv, BFv>(c, a, grid)))
+    if (c->bf16) { // nvqa_set_precision(1): operands rounded to bf16, v_mfma_f32_16x16x32_bf16, f32 accumulate
+        if (d.E == 200) { if (MT == 4) NVQA_PF_GO(200, 4, true); else NVQA_PF_GO(200, 8, true); }
+        else { if (MT == 4) NVQA_PF_GO(512, 4, true); else NVQA_PF_GO(512, 8, true); }
     } else {
-        if (MT == 4) NVQA_TRY((launch_persist_fwd<32, 32, 4>(c, a, grid)));
-        else NVQA_TRY((launch_persist_fwd<32, 32, 8>(c, a, grid)));
+        if (d.E == 200) { if (MT == 4) NVQA_PF_GO(200, 4, false); else NVQA_PF_GO(200, 8, false); }
+        else { if (MT == 4) NVQA_PF_GO(512, 4, false); else NVQA_PF_GO(512, 8, false); }
     }
+#undef NVQA_PF_GO
     NVQA_HIP(hipMemcpyAsync(c->h_pf_err, a.err, 16, hipMemcpyDeviceToHost, c->s));
     return 0;
 }
@@ -703,32 +746,36 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 // layer first; the time-batched weight-gradient GEMMs of a layer start on the low-priority
 // bulk stream as soon as that layer's last step is done.
 // BPTT as one persistent launch (lstm_persist_bwd.h): same eligibility as the forward kernel, L <= 2.
+// column tiles (of 16 units) per workgroup of the persistent BPTT kernel: the bf16 weights take half the registers
+static int persist_bwd_ntn(const nvqa_ctx *c) { return c->bf16 && c->d.L > 1 ? 4 : 2; }
 static int persist_bwd_rows(const nvqa_ctx *c, int *RB)
 {
     const nvqa_dims &d = c->d;
-    if (!persist_rows(c) || !c->persist_bwd_on || d.L > 2) return 0;
-    const int mtiles = (d.B + 15) / 16, NU = d.R / 32, MT = d.L == 1 ? 4 : 7;
+    // NVQA_PERSIST_BWD: 1 on, 0 off; unset: on for bf16 (0.9 -> 0.x ms), off for f32 (it only ties the per-level kernels)
+    const bool on = c->persist_bwd_on < 0 ? c->bf16 : c->persist_bwd_on > 0;
+    if (!persist_rows(c) || !on || d.L > 2) return 0;
+    const int mtiles = (d.B + 15) / 16, NU = d.R / (16 * persist_bwd_ntn(c)), MT = d.L == 1 || c->bf16 ? 4 : 7;
     *RB = (mtiles + MT - 1) / MT;
     if ((2 * d.L - 1) * *RB * NU > c->num_cus || c->num_cus < 256 || (2 * d.L - 1) * *RB > 8 * (32 / NU)) return 0;
     return MT;
 }
 
-template <int GK, int MT>
+template <int GK, int MT, int NTN, bool BF>
 static int launch_persist_bwd(nvqa_ctx *c, const PersistBwdArgs &a, int grid)
 {
-    const size_t lds = PersistBwdGeom<GK, MT>::LDS_BYTES;
+    const size_t lds = PersistBwdGeom<MT, NTN>::LDS_BYTES;
     static int resident = -1;
     if (resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_bwd_persist<GK, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_bwd_persist<GK, MT, NTN, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_bwd_persist<GK, MT>, NVQA_PF_THREADS, lds));
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_bwd_persist<GK, MT, NTN, BF>, NVQA_PF_THREADS, lds));
         resident = nb;
     }
     if (resident < 1 || grid > c->num_cus) {
         set_error("persistent BPTT kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
         return -1;
     }
-    hipLaunchKernelGGL((k_lstm_bwd_persist<GK, MT>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    hipLaunchKernelGGL((k_lstm_bwd_persist<GK, MT, NTN, BF>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -746,20 +793,31 @@ static int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     a.dCT = c->dCT; a.dHT = c->dHT;
     a.nrows = c->nrows; a.sort_idx = c->sort_idx;
     a.tlast = d.arch == NVQA_ARCH2 ? c->tinfo + 1 : nullptr;
-    a.B = B; a.R = R; a.L = L; a.TS = TS; a.RB = RB; a.NU = R / 32;
+    a.B = B; a.R = R; a.L = L; a.TS = TS; a.RB = RB; a.NU = R / (16 * persist_bwd_ntn(c));
     a.dr = dr;
+    if (c->bf16) { // bf16 image of dG, [L][TS*B][4R] (first use of the bf16 instance)
+        const size_t gs = (size_t)TS * B * 4 * R;
+        if (!c->dg_b16) NVQA_HIP(hipMalloc((void **)&c->dg_b16, (size_t)L * gs * 2));
+        for (int l = 0; l < L; ++l) a.Gb[l] = c->dg_b16 + l * gs;
+    }
     { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
     { static const int dbg = [] { const char *e = getenv("NVQA_PB_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     const size_t n_rec = (size_t)L * RB * TS, n_up = (size_t)L * RB * a.NU * TS;
     if (n_rec + n_up + 4 > c->pb_cnt_words) { set_error("persistent BPTT: counter block too small"); return -1; }
     a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = c->pb_cnt + c->pb_cnt_words - 4;
+    a.ts = c->pf_ts + 1024;
     const int grid = 256; // 8 XCDs x 32 slots (lstm_persist_bwd.h maps groups to XCDs); (2L-1) * RB * NU of them have work
     double flops = 0;
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * R * ((double)(TS - 1) + (l + 1 < L ? TS : 0));
     ProfScope ps(c, PF_LSTM_BWD, flops, 0);
     NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
-    if (MT == 4) NVQA_TRY((launch_persist_bwd<32, 4>(c, a, grid)));
-    else NVQA_TRY((launch_persist_bwd<32, 7>(c, a, grid)));
+    if (c->bf16) {
+        if (L == 1) NVQA_TRY((launch_persist_bwd<16, 4, 2, true>(c, a, grid)));
+        else NVQA_TRY((launch_persist_bwd<16, 4, 4, true>(c, a, grid)));
+    } else {
+        if (MT == 4) NVQA_TRY((launch_persist_bwd<32, 4, 2, false>(c, a, grid)));
+        else NVQA_TRY((launch_persist_bwd<32, 7, 2, false>(c, a, grid)));
+    }
     NVQA_HIP(hipMemcpyAsync(c->h_pf_err + 4, a.err, 16, hipMemcpyDeviceToHost, c->s));
     return 0;
 }

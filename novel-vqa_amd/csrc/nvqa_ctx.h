@@ -112,8 +112,11 @@ struct nvqa_ctx {
     int num_cus = 0;
     unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed before every launch)
     size_t pf_cnt_words = 0;
+    unsigned long long *pf_ts = nullptr; // debug timestamps of the persistent kernels (NVQA_PF_DBG & 32)
+    unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd.h)
+    unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the err records (forward: words 0-3, BPTT: words 4-7)
-    bool persist_bwd_on = false;  // BPTT as one persistent launch (lstm_persist_bwd.h)
+    int persist_bwd_on = -1;       // BPTT as one persistent launch (lstm_persist_bwd.h)
     unsigned *pb_cnt = nullptr;   // its counters + err record
     size_t pb_cnt_words = 0;
     float *pb_pup = nullptr;      // [L-1][TS*B][R] products handed from the UP role to the cells of the layer below

@@ -1,4 +1,9 @@
-timeout -k 5 300 python -m pytest tests/test_gpu_parity_r2.py -m gpu -q -x -k "headline or persistent or satbias" 2>&1 | tail -3
-for dbg in 0 1 3; do
-NVQA_PB_DBG=$dbg timeout -k 5 100 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('dbg',$dbg, d['ms_per_step'], d['kernel_ms_per_step']['lstm_step_bwd'])"
+#!/bin/bash
+# ablation of the persistent kernels (NVQA_PF_DBG / NVQA_PB_DBG bits: 1 no flag waits, 2 no cell, 8 loads without traffic)
+# usage: pfdbg.sh "<bench flags>" PF|PB dbg...
+flags="$1"; var="NVQA_$2_DBG"; shift; shift
+for d in "$@"; do
+  env $var=$d python bench.py $flags --no-secondary --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import sys, json
+r = json.loads(sys.stdin.read()); k = r['kernel_ms_per_step']; print('$var=$d', 'step', r['ms_per_step'], 'fwd', k['lstm_step_fwd'], 'bwd', k['lstm_step_bwd'])"
 done

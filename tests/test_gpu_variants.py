@@ -88,8 +88,8 @@ def test_evaluate_validation_loss_and_multiple_choice(pkg, orc):
     """nvqa_evaluate = what validate() (002_train_baseline.lua:337-381) and the test script (004_eval_model.lua:233,
     259-271) take from an evaluate-mode forward: mean cross-entropy of the rows, open-ended argmax, and the
     multiple-choice answer among the non-zero candidates (first on ties, as torch.max over the slot order)."""
-    for kw in (dict(arch=1, B=24, T=7, V=40, E=16, R=16, L=2, I=32, C=24, A=30),
-               dict(arch=2, B=24, T=6, V=40, E=16, R=16, L=1, I=32, C=4, A=30)):
+    for kw in (dict(arch=1, B=24, T=7, V=40, E=16, R=16, L=2, I=32, C=24, A=32),
+               dict(arch=2, B=24, T=6, V=40, E=16, R=16, L=1, I=32, C=4, A=32)):
         d = orc.make_dims(**kw)
         params = orc.synth_params(d) * np.float32(3.0)
         tok, lens, img, lab = orc.synth_batch(d, full_length=False)
