@@ -1,4 +1,5 @@
-"""Calibration of the full-size bf16 parity tolerances (tests/test_gpu_bf16.py): distance of the HIP bf16 step to the\noracle in operand-rounding mode and to the f32 result, max-norm and L2, per parameter segment, at T = 26 and at 2-3 steps."""
+"""(script, not a test: python tests/bf16_distance.py on the GPU box) Calibration of the full-size bf16 parity tolerances (tests/test_gpu_bf16.py): distance of the HIP bf16 step to the
+oracle in operand-rounding mode and to the f32 result, max-norm and L2, per parameter segment, at T = 26 and at 2-3 steps."""
 import os, sys, numpy as np
 sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "tests")]
 os.environ["NVQA_PERSIST"] = "1"

@@ -82,7 +82,7 @@ def test_bf16_full_size(pkg, orc, name):
     tests/test_oracle_bf16_cascade.py shows it on the CPU alone: the C oracle against ITSELF, f32 versus f64 arithmetic
     (1.4e-7 apart without rounding), ends 0.28 - 0.30 of that distance apart in the logits.  The HIP routes (hardware
     exp / rcp forms in the cell, ~1e-6 from libm on small arguments) sit at 0.2 - 0.55 from the oracle and from each other
-    (novel-vqa_amd/tools/bf16_distance.py; the measured values land in gpurun_out/parity_r02.jsonl).  Hence:
+    (tests/bf16_distance.py; the measured values land in gpurun_out/parity_r02.jsonl).  Hence:
       * loss 1e-4 relative, every gradient segment within 5e-3 of its largest entry (as in the scaled-down cases), logits
         within 3e-3 of the largest logit;
       * every weight-gradient segment is closer (L2) to the bf16 oracle than 0.75 x its distance to the f32 result, and
