@@ -452,6 +452,210 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
 }
 
 // ---------------------------------------------------------------------------------
+// Embedding / lookup-table gradient by token segments (the default; k_emb_bwd above remains for vocabularies whose
+// index does not fit one workgroup's LDS).  k_emb_bwd has every workgroup scan the whole packed token list (V / 16 x 4
+// scans of T*B tokens: 0.14 ms on arch2 whatever the batch) and sums a frequent word's rows in one wave, 8 at a time
+// (arch2's START token has B = 512 of them in EVERY batch; real questions add "what", "is", "the").  Here
+//   k_tok_index   (one workgroup, on a side stream under the forward pass) sorts the packed positions by token:
+//                 seg_start[v] .. seg_start[v+1] delimit token v's positions in perm[], ascending;
+//   k_emb_bwd_seg (one wave per token) sums the rows of its positions in that order;
+//   k_emb_bwd_long: a token with more than NVQA_ES_SHORT occurrences is cut into NVQA_ES_CHUNKS equal chunks summed by
+//                 different waves into partial rows; the wave that arrives last (agent-scope counter) adds the partials
+//                 in chunk order.
+// The summation order is fixed by perm and the chunk boundaries, so the result is bit-reproducible; no atomics on data.
+// ---------------------------------------------------------------------------------
+#define NVQA_ES_SHORT 32   // occurrences one wave sums by itself
+#define NVQA_ES_CHUNKS 16  // a longer segment is cut into this many chunks
+#define NVQA_TI_THREADS 1024
+#define NVQA_TI_NPT 16     // packed positions per thread of the index kernel: T*B <= 16384
+__host__ __device__ inline size_t tok_index_lds(int VT, int NP) { return (size_t)VT * 4 + (size_t)NP * 4 + NVQA_TI_THREADS * 4 + 16; }
+__global__ __launch_bounds__(NVQA_TI_THREADS) void k_tok_index(const int32_t *ptok, int NP, int VT, int32_t *seg_start /*[VT+1]*/,
+                                                               uint16_t *perm /*[NP]*/, int32_t *long_tok /*[NP / SHORT + 1]*/,
+                                                               unsigned *done /*[NP / SHORT + 1]*/, int32_t *nlong_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned ti_smem[];
+    unsigned *cnt = ti_smem;              // [VT] counts -> exclusive prefix sums = placement cursors -> segment ENDS
+    unsigned *part = cnt + VT;            // [threads] scan partials
+    unsigned *nlong = part + NVQA_TI_THREADS;
+    unsigned *tmp = nlong + 4;            // [NP] (token << 16 | position), grouped by token, unordered inside a group
+    const int tid = threadIdx.x;
+    int w[NVQA_TI_NPT]; // this thread's tokens: one batch of independent loads
+#pragma unroll
+    for (int i = 0; i < NVQA_TI_NPT; ++i) {
+        const int k = tid + i * NVQA_TI_THREADS;
+        const int x = k < NP ? ptok[k] : -1;
+        w[i] = x >= 0 && x < VT ? x : -1;
+    }
+    for (int v = tid; v < VT; v += NVQA_TI_THREADS) cnt[v] = 0;
+    if (tid == 0) *nlong = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NVQA_TI_NPT; ++i)
+        if (w[i] >= 0) atomicAdd(&cnt[w[i]], 1u);
+    __syncthreads();
+    // exclusive scan: thread -> a contiguous run of tokens
+    const int per = (VT + NVQA_TI_THREADS - 1) / NVQA_TI_THREADS, v0 = tid * per, v1 = min(VT, v0 + per);
+    unsigned sum = 0;
+    for (int v = v0; v < v1; ++v) sum += cnt[v];
+    // inclusive scan of the 1024 partials: inside each wave by shuffles, then the 16 wave totals
+    unsigned inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned x = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += x;
+    }
+    if ((tid & 63) == 63) part[tid >> 6] = inc;
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned t0 = tid < NVQA_TI_THREADS / 64 ? part[tid] : 0u;
+        unsigned t = t0;
+#pragma unroll
+        for (int o = 1; o < NVQA_TI_THREADS / 64; o <<= 1) {
+            const unsigned x = __shfl_up(t, o, 64);
+            if (tid >= o) t += x;
+        }
+        if (tid < NVQA_TI_THREADS / 64) part[64 + tid] = t - t0; // exclusive prefix of the wave totals
+        if (tid == NVQA_TI_THREADS / 64 - 1) part[128] = t;      // grand total
+    }
+    __syncthreads();
+    unsigned run = part[64 + (tid >> 6)] + inc - sum;
+    for (int v = v0; v < v1; ++v) {
+        const unsigned n = cnt[v];
+        cnt[v] = run;
+        seg_start[v] = (int)run;
+        if (n > NVQA_ES_SHORT) { // (which slot a token gets does not matter)
+            const unsigned slot = atomicAdd(nlong, 1u);
+            long_tok[slot] = v;
+            done[slot] = 0;
+        }
+        run += n;
+    }
+    const unsigned total = part[128];
+    if (tid == NVQA_TI_THREADS - 1) seg_start[VT] = (int)total;
+    __syncthreads();
+    if (tid == 0) *nlong_out = (int)*nlong;
+#pragma unroll
+    for (int i = 0; i < NVQA_TI_NPT; ++i)
+        if (w[i] >= 0) tmp[atomicAdd(&cnt[w[i]], 1u)] = ((unsigned)w[i] << 16) | (unsigned)(tid + i * NVQA_TI_THREADS);
+    __syncthreads();
+    // order inside a group: rank of each position among its group (groups are short, or a few long ones); cnt[v] is now
+    // the END of token v's group, so its start is the end of the group before it
+    for (unsigned p = tid; p < total; p += NVQA_TI_THREADS) {
+        const unsigned x = tmp[p], v = x >> 16;
+        const unsigned s = v ? cnt[v - 1] : 0u, e = cnt[v];
+        unsigned rank = 0;
+        for (unsigned q = s; q < e; ++q) rank += tmp[q] < x ? 1u : 0u;
+        perm[s + rank] = (uint16_t)(x & 0xffffu);
+    }
+}
+
+// rows of positions [lo, hi) of perm, summed in that order: 8 rows in flight, both column passes of a lane together
+template <int NPASS>
+__device__ __forceinline__ void emb_seg_sum(const uint16_t *perm, int lo, int hi, const float *X, const float *dX, const int32_t *sort_idx,
+                                            int B, int T, int E, const Drop &dr, int plain, int lane, float4 (&acc)[NPASS])
+{
+    const int E4 = E / 4;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = lo; i0 < hi; i0 += 64) { // the positions of up to 64 rows: one coalesced load, then broadcasts
+        const int mine = i0 + lane < hi ? (int)perm[i0 + lane] : 0;
+        const int nb = min(64, hi - i0);
+        for (int j0 = 0; j0 < nb; j0 += 8) {
+            float4 a[8][NPASS];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = __shfl(mine, min(j0 + j, 63), 64);
+                const bool on = j0 + j < nb;
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) {
+                    const int c4 = lane + 64 * p;
+                    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (on && c4 < E4) {
+                        const size_t g = (size_t)k * E + 4 * c4;
+                        d = *reinterpret_cast<const float4 *>(dX + g);
+                        if (!plain) { // arch1: through Dropout and Tanh of the embedding (002_train_baseline.lua:319-320)
+                            const float4 x = *reinterpret_cast<const float4 *>(X + g);
+                            const int t = k / B, r = k % B;
+                            const uint64_t base = ((uint64_t)sort_idx[r] * T + t) * E + 4 * c4;
+                            d.x = dr.scale(NVQA_SITE_EMB, base) * (d.x * (1.0f - x.x * x.x));
+                            d.y = dr.scale(NVQA_SITE_EMB, base + 1) * (d.y * (1.0f - x.y * x.y));
+                            d.z = dr.scale(NVQA_SITE_EMB, base + 2) * (d.z * (1.0f - x.z * x.z));
+                            d.w = dr.scale(NVQA_SITE_EMB, base + 3) * (d.w * (1.0f - x.w * x.w));
+                        }
+                    }
+                    a[j][p] = d;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) { acc[p].x += a[j][p].x; acc[p].y += a[j][p].y; acc[p].z += a[j][p].z; acc[p].w += a[j][p].w; }
+        }
+    }
+}
+
+// tokens with at most NVQA_ES_SHORT occurrences (absent ones included: their row is zero): one wave per token
+template <int NPASS>
+__global__ __launch_bounds__(256) void k_emb_bwd_seg(const int32_t *seg_start, const uint16_t *perm, const float *X, const float *dX,
+                                                     const int32_t *sort_idx, int B, int T, int VT, int E, Drop dr, float *dWeT /*[VT][E]*/, int plain)
+{
+    const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= VT) return;
+    const int s0 = seg_start[v], n = seg_start[v + 1] - s0;
+    if (n > NVQA_ES_SHORT) return; // k_emb_bwd_long
+    float4 acc[NPASS];
+    emb_seg_sum<NPASS>(perm, s0, s0 + n, X, dX, sort_idx, B, T, E, dr, plain, lane, acc);
+    float4 *row = reinterpret_cast<float4 *>(dWeT + (size_t)v * E);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+        if (lane + 64 * p < E / 4) row[lane + 64 * p] = acc[p];
+}
+
+// the frequent tokens: wave (slot, chunk) sums its chunk into a partial row; the last of a token's NVQA_ES_CHUNKS waves to
+// arrive adds the partials in chunk order.  Grid = every possible slot; slots beyond *nlong leave at once.
+template <int NPASS>
+__global__ __launch_bounds__(256) void k_emb_bwd_long(const int32_t *seg_start, const uint16_t *perm, const int32_t *long_tok,
+                                                      const int32_t *nlong, unsigned *done, float *partial /*[slots][CHUNKS][E]*/,
+                                                      unsigned partial_bytes, const float *X, const float *dX, const int32_t *sort_idx, int B, int T,
+                                                      int E, Drop dr, float *dWeT, int plain)
+{
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = wv / NVQA_ES_CHUNKS, ch = wv % NVQA_ES_CHUNKS;
+    if (slot >= *nlong) return;
+    const int v = long_tok[slot];
+    const int s0 = seg_start[v], n = seg_start[v + 1] - s0;
+    const int len = (n + NVQA_ES_CHUNKS - 1) / NVQA_ES_CHUNKS;
+    const int lo = min(s0 + n, s0 + ch * len), hi = min(s0 + n, lo + len);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r_part = __builtin_amdgcn_make_buffer_rsrc(partial, 0, (int)partial_bytes, 0x00020000);
+    float4 acc[NPASS];
+    emb_seg_sum<NPASS>(perm, lo, hi, X, dX, sort_idx, B, T, E, dr, plain, lane, acc);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+        if (lane + 64 * p < E / 4)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(acc[p].x), __float_as_uint(acc[p].y), __float_as_uint(acc[p].z), __float_as_uint(acc[p].w)},
+                                                   r_part, (unsigned)(((size_t)(slot * NVQA_ES_CHUNKS + ch) * E + 4 * (lane + 64 * p)) * 4), 0, 16 /* sc1 */);
+    // hand-off of the partial rows (MI355X_MICROARCH.md "Valid forms": sc1 write-through stores, drained by the storing
+    // wave, then ONE agent-scope add by one of its lanes; the wave whose add came last -- told by the value returned --
+    // reads all partials with sc1 buffer loads after that add has returned)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(done + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != NVQA_ES_CHUNKS - 1) return;
+    float4 *row = reinterpret_cast<float4 *>(dWeT + (size_t)v * E);
+    for (int c4 = lane; c4 < E / 4; c4 += 64) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int cc = 0; cc < NVQA_ES_CHUNKS; ++cc) {
+            const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(r_part, (unsigned)(((size_t)(slot * NVQA_ES_CHUNKS + cc) * E + 4 * c4) * 4), 0, 16 /* sc1 */);
+            sum.x += __uint_as_float(x[0]); sum.y += __uint_as_float(x[1]); sum.z += __uint_as_float(x[2]); sum.w += __uint_as_float(x[3]);
+        }
+        row[c4] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // arch2 (003_train_vqa_arch2/misc/Encoder_lstm.lua:152-227): the encoder runs T+2 steps;
 // step 0 = projected image, step 1 = START token (row V of the lookup table), step t >= 2 =
 // token t-2 with null (0) rewritten to token 1 (:197).  It stops at the first all-null time

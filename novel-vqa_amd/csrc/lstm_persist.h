@@ -119,7 +119,13 @@ __device__ __forceinline__ unsigned pf_pack_bf16(float x, float y) // round-to-n
 // tiles of 16 rows per workgroup.
 // INB: the input segment is read from a bf16 image (layers >= 1 of the bf16 instance: Ub); the recurrent segment is
 // (Hb) whenever BF.
-template <int G0, int G1, int MT, bool BF, bool INB>
+// RAG: ragged arch1 batches (rows sorted by length, row r active from step T - len[r] on: nrows[t] grows with t).  The
+// rows of a block are dealt round-robin, so at step t the active rows of EVERY block are a prefix of its local rows and
+// all blocks have the same share of them: the row-tile pairs beyond ceil(active / 16) skip their MFMAs (a wave-uniform
+// branch per pair; it costs the full-length case 8 %, which therefore keeps the branch-free instance).  Loads, LDS
+// traffic, barriers and flags do not change (inactive rows arrive as zeros), so the step time follows the MFMA count,
+// i.e. nrows[t].
+template <int G0, int G1, int MT, bool BF, bool INB, bool RAG>
 __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const int l, const int rb, const int ut,
                                                   float *smem)
 {
@@ -139,10 +145,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS;
     const int Kin = l == 0 ? a.E : R;
-    // Rows are dealt to the row blocks round-robin: local row i of block rb is sorted batch row rb + RB i.  (The host
-    // launches this kernel only for batches whose rows are all active whenever any is -- equal-length arch1 batches and
-    // arch2 -- so every row tile always has work; a ragged instance that skipped row tiles per step needed a branch per
-    // MFMA pair, 8 % on the full-length case, and was dropped.  Ragged batches take the per-level kernels.)
+    // Rows are dealt to the row blocks round-robin: local row i of block rb is sorted batch row rb + RB i.
     const int RBn = a.RB;
     const int u0 = ut * 16;
 
@@ -220,6 +223,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     const unsigned step_bytesb = (unsigned)B * R * 2, rstrideb = 32u * RBn * R * 2, toffb = (growb * R + 8 * bkq) * 2;
     const int jmaxb = (int)growb < B ? (B - (int)growb + 32 * RBn - 1) / (32 * RBn) : 0;
 
+    int mt_cur = MT, mt_nxt = MT; // RAG: row tiles with active rows at this step / at the next one
     pf_u32x4 stg[D][MT];
     unsigned pend = 0; // value of the counter the next flagged chunk depends on, requested a chunk ahead of its use
     // ask for the counter that chunk q of step t waits for (always a load -- of counter 0 when nothing is awaited --
@@ -236,8 +240,11 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     // memory): a load under a runtime branch makes hipcc wait vmcnt(0) at the join, i.e. for the chunk just requested
     // instead of the one requested an iteration ago (cdna_hip_programming.md section 5, trap (c)).
     unsigned pf_o0 = PF_OOB; // offset of the thread's first piece of the chunk being requested
-    auto prefetch_begin = [&](int t, auto q_tag, bool en) {
+    int pf_jlim = 0, pf_jlimb = 0; // pieces of that chunk with rows worth loading (RAG: the active row tiles of ITS step)
+    auto prefetch_begin = [&](int t, auto q_tag, bool en, bool next_step = false) {
         constexpr int q = decltype(q_tag)::value;
+        pf_jlim = RAG ? min(jmax, next_step ? mt_nxt : mt_cur) : jmax;
+        pf_jlimb = RAG ? min(jmaxb, ((next_step ? mt_nxt : mt_cur) + 1) >> 1) : jmaxb; // (a bf16-image piece spans two row tiles)
         constexpr bool s1 = q >= NC0;
         // (step 0 multiplies the recurrent chunks too: slice 0 of Hs holds h_{-1} = 0, or the carried h0 of
         // NVQA_QUIRK_H0 -- one step of 26 with 50 % more MFMAs is cheaper than a second copy of the unrolled chunk
@@ -278,10 +285,10 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         for (int j = decltype(j0_tag)::value; j < decltype(j1_tag)::value && j < MT; ++j) {
             if constexpr (s1 ? BF : INB) {
                 if (j & 1) continue;
-                const unsigned off = (j >> 1) < jmaxb ? pf_o0 + (unsigned)(j >> 1) * rstrideb : PF_OOB;
+                const unsigned off = (j >> 1) < pf_jlimb ? pf_o0 + (unsigned)(j >> 1) * rstrideb : PF_OOB;
                 stg[SET][j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rec : r_in, off, 0, 16 /* sc1 */);
             } else {
-                const unsigned off = j < jmax ? pf_o0 + (unsigned)j * (s1 ? rstride1 : rstride0) : PF_OOB;
+                const unsigned off = j < pf_jlim ? pf_o0 + (unsigned)j * (s1 ? rstride1 : rstride0) : PF_OOB;
                 stg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rec : r_in, off, 0, 16 /* sc1 */);
             }
         }
@@ -340,23 +347,28 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
             };
             auto pair = [&](auto mp_tag) {
                 constexpr int mp = decltype(mp_tag)::value;
-                if constexpr (!BF) {
+                if (!RAG || mp < mt_cur) {
+                    if constexpr (!BF) {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
+                        for (int w = 0; w < 4; ++w)
+#pragma unroll
+                            for (int m = mp; m < mp + 2 && m < MT; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(pf_f32x4, af[m])[w],
+                                                                              __builtin_bit_cast(pf_f32x4, bw[GB + g])[w], acc[m], 0, 0, 0);
+                    } else {
 #pragma unroll
                         for (int m = mp; m < mp + 2 && m < MT; ++m)
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(pf_f32x4, af[m])[w],
-                                                                          __builtin_bit_cast(pf_f32x4, bw[GB + g])[w], acc[m], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int m = mp; m < mp + 2 && m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, af[m]),
-                                                                         __builtin_bit_cast(pf_bf16x8, bw[GB + g]), acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, af[m]),
+                                                                             __builtin_bit_cast(pf_bf16x8, bw[GB + g]), acc[m], 0, 0, 0);
+                    }
                 }
                 const float *src = g + 1 < NG ? cur : nxt;
                 constexpr int gn = g + 1 < NG ? g + 1 : 0;
+                // (the fragments fetched by the last group of a step are the next step's: its activity decides)
+                if (!RAG || mp < (q == NT - 1 && g == NG - 1 ? mt_nxt : mt_cur)) {
 #pragma unroll
-                for (int m = mp; m < mp + 2 && m < MT; ++m) af[m] = frag_at(src, m, gn);
+                    for (int m = mp; m < mp + 2 && m < MT; ++m) af[m] = frag_at(src, m, gn);
+                }
                 hook(mp_tag); // a piece of the next chunks' housekeeping, under this pair's MFMAs
                 // keep the refill (and the piece) HERE: left alone, hipcc sinks these reads to just above their first use
                 // (shorter live range) and every pair then opens with an exposed LDS round trip -- 15 % of the step
@@ -489,6 +501,14 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             const bool more = t + 1 < t_hi;
+            if constexpr (RAG) {
+                auto mt_of = [&](int tt) {
+                    const int nr = a.nrows[tt], nloc = nr > rb ? (nr - rb + RBn - 1) / RBn : 0;
+                    return __builtin_amdgcn_readfirstlane(min(MT, (nloc + 15) >> 4));
+                };
+                mt_cur = mt_of(t);
+                mt_nxt = more ? mt_of(t + 1) : mt_cur;
+            }
             auto iter = [&](auto q_tag) {
                 constexpr int q = decltype(q_tag)::value;
                 constexpr int NG = decltype(chunk_groups(q_tag))::value;
@@ -499,7 +519,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
                 //   fragments of chunk q+1).  Chunks with fewer groups keep the order of the remaining pieces.
                 // chunk q+2: flag check + offsets now, its loads two per MFMA pair under group 0
                 if constexpr (q + D < NT) prefetch_begin(t, std::integral_constant<int, q + D>{}, true);
-                else prefetch_begin(more ? t + 1 : t, std::integral_constant<int, q + D - NT>{}, more);
+                else prefetch_begin(more ? t + 1 : t, std::integral_constant<int, q + D - NT>{}, more, true);
                 constexpr int QN = q + D < NT ? q + D : q + D - NT; // index of that chunk inside its step
                 auto none = [](auto) {};
                 auto loads = [&](auto mp_tag) {
@@ -549,7 +569,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
 
 // KA: K of layer 0's input (E, rounded up to the group width); workgroup id -> (layer, row block, unit tile): the NU unit
 // tiles of one (layer, row block) share an id modulo the group count, i.e. one XCD when there are 8 groups.
-template <int KA, int KR, int MT, bool BF>
+template <int KA, int KR, int MT, bool BF, bool RAG>
 __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_fwd_persist(PersistFwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float pf_smem[];
@@ -558,8 +578,8 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_fwd_persist(Persist
     const int grp = blockIdx.x % groups, ut = blockIdx.x / groups;
     const int l = grp / a.RB, rb = grp % a.RB;
     if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4] = wall_clock64();
-    if (l == 0) persist_fwd_layer<G0A, GR, MT, BF, false>(a, l, rb, ut, pf_smem);
-    else persist_fwd_layer<GR, GR, MT, BF, BF>(a, l, rb, ut, pf_smem);
+    if (l == 0) persist_fwd_layer<G0A, GR, MT, BF, false, RAG>(a, l, rb, ut, pf_smem);
+    else persist_fwd_layer<GR, GR, MT, BF, BF, RAG>(a, l, rb, ut, pf_smem);
     if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
 }
 template <int KA, int KR, int MT, bool BF> constexpr size_t persist_fwd_lds()

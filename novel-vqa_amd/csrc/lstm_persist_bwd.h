@@ -58,7 +58,9 @@ template <int MT, int NTN> struct PersistBwdGeom {
 
 // GK: K groups (= chunks) per gate: R / 16 (f32), R / 32 (bf16); MT row tiles of 16 rows and NTN column tiles of 16 units
 // per workgroup
-template <int GK, int MT, int NTN, bool BF>
+// RAG: ragged arch1 batches -- as in lstm_persist.h, the row tiles of a block without rows active at step s skip
+// their MFMAs and their A loads
+template <int GK, int MT, int NTN, bool BF, bool RAG>
 __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(PersistBwdArgs a)
 {
     typedef PersistBwdGeom<MT, NTN> GE;
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
 
     pf_u32x4 stg[D][MT];
     unsigned pf_o0 = PF_OOB;
+    int mt_cur = MT; // RAG: row tiles with rows active at this step
     // A slice `sa` of Gt[la] (dG of step sa), K group g; en = false: zeros without memory traffic
     auto prefetch_begin = [&](int sa, auto g_tag, bool en) {
         constexpr int g = decltype(g_tag)::value;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
         constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
         for (int j = decltype(j0_tag)::value; j < decltype(j1_tag)::value && j < MT; ++j) {
-            const unsigned off = j < jmax ? pf_o0 + (unsigned)j * rstride : PF_OOB;
+            const unsigned off = j < (RAG ? min(jmax, mt_cur) : jmax) ? pf_o0 + (unsigned)j * rstride : PF_OOB;
             stg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(r_a, off, 0, 16 /* sc1 */);
         }
     };
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
     // MFMAs of row tiles mp, mp+1 for K group g (f32: 2 x NTN x 4, an accumulator is reused every 2 NTN-th MFMA)
     auto pair = [&](auto g_tag, auto mp_tag) {
         constexpr int g = decltype(g_tag)::value, mp = decltype(mp_tag)::value;
+        if (RAG && mp >= mt_cur) return;
         if constexpr (!BF) {
 #pragma unroll
             for (int w = 0; w < 4; ++w)
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
         // first two of the thread's NE items -- as many as fit beside the resident weights; the other items are requested
         // as the first two are consumed.  Requested in the epilogue they were 4 exposed HBM round trips per step (4.4 us).
         const int nr = a.nrows[s];
+        if constexpr (RAG) mt_cur = __builtin_amdgcn_readfirstlane(min(MT, ((nr > rb ? (nr - rb + RBn - 1) / RBn : 0) + 15) >> 4));
         const bool head_now = a.tlast ? (*a.tlast == s) : (s == TS - 1);
         pf_f32x4 e_ig[2], e_fg[2], e_og[2], e_gg[2], e_cc[2], e_cp[2];
         int e_si[2];

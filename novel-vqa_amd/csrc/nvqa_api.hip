@@ -245,6 +245,9 @@ static int create_impl(nvqa_ctx *c)
         NVQA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         NVQA_HIP(hipStreamCreateWithPriority(&c->s, hipStreamNonBlocking, greatest));
         NVQA_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, greatest));
+        NVQA_HIP(hipStreamCreateWithFlags(&c->sx, hipStreamNonBlocking));
+        NVQA_HIP(hipEventCreateWithFlags(&c->evTok, hipEventDisableTiming));
+        NVQA_HIP(hipEventCreateWithFlags(&c->evIdx, hipEventDisableTiming));
         for (int i = 0; i < 3 + NVQA_MAX_LAYERS; ++i) NVQA_HIP(hipEventCreateWithFlags(&c->evSeg[i], hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evComm, hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
@@ -265,6 +268,18 @@ static int create_impl(nvqa_ctx *c)
     NVQA_TRY(dalloc(&c->nrows, TS));
     NVQA_TRY(dalloc(&c->ptok, TB));
     NVQA_TRY(dalloc(&c->tinfo, 2));
+    { // token-segment index for the embedding gradient (kernels.h: k_tok_index)
+        const char *e = getenv("NVQA_EMB_SEG");
+        c->tok_seg = !(e && e[0] == '0');
+        const size_t VT = d.V + 1, slots = TB / NVQA_ES_SHORT + 2;
+        NVQA_TRY(dalloc(&c->seg_start, VT + 1));
+        NVQA_HIP(hipMemsetAsync(c->seg_start, 0, (VT + 1) * 4, c->s));
+        NVQA_TRY(dalloc(&c->pslot, slots + 4));
+        NVQA_TRY(dalloc(&c->perm, TB));
+        NVQA_TRY(dalloc(&c->seg_done, slots));
+        c->seg_part_bytes = slots * NVQA_ES_CHUNKS * E * sizeof(float);
+        NVQA_TRY(dalloc(&c->seg_part, slots * NVQA_ES_CHUNKS * E));
+    }
     NVQA_TRY(dalloc(&c->X0, TB * E));
     NVQA_TRY(dalloc(&c->dX0, TB * E));
     for (size_t l = 0; l < L; ++l) {
@@ -352,7 +367,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
                     c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT, c->mc,
-                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F};
+                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int l = 0; l < NVQA_MAX_LAYERS; ++l) {
@@ -374,6 +389,9 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     for (hipEvent_t e : c->evSeg)
         if (e) (void)hipEventDestroy(e);
     if (c->sc) (void)hipStreamDestroy(c->sc);
+    if (c->sx) (void)hipStreamDestroy(c->sx);
+    if (c->evTok) (void)hipEventDestroy(c->evTok);
+    if (c->evIdx) (void)hipEventDestroy(c->evIdx);
     if (c->s) (void)hipStreamDestroy(c->s);
     delete c;
     return 0;
@@ -582,22 +600,22 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
 // ------------------------------------------------------------------------------------
 // The whole forward unroll as one persistent, weight-stationary launch (lstm_persist.h).  Eligible shapes: the two the
 // reference trains (R = 512 with E = 200 [arch1] or E = 512 [arch2]) on a device with one CU per workgroup.
-template <int KA, int KR, int MT, bool BF>
+template <int KA, int KR, int MT, bool BF, bool RAG>
 static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 {
     const size_t lds = persist_fwd_lds<KA, KR, MT, BF>();
     static int resident = -1; // per instantiation: workgroups of this kernel one CU can hold
     if (resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<KA, KR, MT, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<KA, KR, MT, BF, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<KA, KR, MT, BF>, NVQA_PF_THREADS, lds));
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<KA, KR, MT, BF, RAG>, NVQA_PF_THREADS, lds));
         resident = nb;
     }
     if (resident < 1 || grid > c->num_cus) { // the workgroups wait for each other: all of them must be resident at once
         set_error("persistent LSTM kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
         return -1;
     }
-    hipLaunchKernelGGL((k_lstm_fwd_persist<KA, KR, MT, BF>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    hipLaunchKernelGGL((k_lstm_fwd_persist<KA, KR, MT, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -606,9 +624,7 @@ static int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT)
 {
     const nvqa_dims &d = c->d;
     if (!c->persist_on || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
-    // every row must be active whenever any row is: arch2 always (all rows run to tmax), arch1 when the host knows that
-    // all questions of the batch have one length; ragged arch1 batches take the per-level kernels
-    if (d.arch == NVQA_ARCH1 && !c->batch_uniform) return 0;
+    // (arch2 and equal-length arch1 batches: every row is active whenever any is; ragged arch1 batches: the RAG instance)
     const int NU = d.R / 16;
     for (int MT : {4, 8}) { // the smallest row block that still gives every workgroup its own CU
         const int RB = (d.B + 16 * MT - 1) / (16 * MT);
@@ -657,13 +673,24 @@ static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);
     ProfScope ps(c, PF_LSTM_FWD, flops, 0);
     NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s));
-#define NVQA_PF_GO(KA, MTv, BFv) NVQA_TRY((launch_persist_fwd<KA, 512, MTv, BFv>(c, a, grid)))
-    if (c->bf16) { // nvqa_set_precision(1): operands rounded to bf16, v_mfma_f32_16x16x32_bf16, f32 accumulate
-        if (d.E == 200) { if (MT == 4) NVQA_PF_GO(200, 4, true); else NVQA_PF_GO(200, 8, true); }
-        else { if (MT == 4) NVQA_PF_GO(512, 4, true); else NVQA_PF_GO(512, 8, true); }
+    // ragged arch1 batch (or lengths known only on the device: the dataset route of a ragged dataset): the instance that
+    // skips the MFMAs of row tiles without active rows
+    const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform;
+#define NVQA_PF_GO(KA, MTv, BFv, RAGv) NVQA_TRY((launch_persist_fwd<KA, 512, MTv, BFv, RAGv>(c, a, grid)))
+    if (d.E == 200) { // arch1
+        if (c->bf16) {
+            if (rag) { if (MT == 4) NVQA_PF_GO(200, 4, true, true); else NVQA_PF_GO(200, 8, true, true); }
+            else { if (MT == 4) NVQA_PF_GO(200, 4, true, false); else NVQA_PF_GO(200, 8, true, false); }
+        } else {
+            if (rag) { if (MT == 4) NVQA_PF_GO(200, 4, false, true); else NVQA_PF_GO(200, 8, false, true); }
+            else { if (MT == 4) NVQA_PF_GO(200, 4, false, false); else NVQA_PF_GO(200, 8, false, false); }
+        }
+    } else if (rag) { // (an arch1 model with E = 512)
+        if (c->bf16) { if (MT == 4) NVQA_PF_GO(512, 4, true, true); else NVQA_PF_GO(512, 8, true, true); }
+        else { if (MT == 4) NVQA_PF_GO(512, 4, false, true); else NVQA_PF_GO(512, 8, false, true); }
     } else {
-        if (d.E == 200) { if (MT == 4) NVQA_PF_GO(200, 4, false); else NVQA_PF_GO(200, 8, false); }
-        else { if (MT == 4) NVQA_PF_GO(512, 4, false); else NVQA_PF_GO(512, 8, false); }
+        if (c->bf16) { if (MT == 4) NVQA_PF_GO(512, 4, true, false); else NVQA_PF_GO(512, 8, true, false); }
+        else { if (MT == 4) NVQA_PF_GO(512, 4, false, false); else NVQA_PF_GO(512, 8, false, false); }
     }
 #undef NVQA_PF_GO
     NVQA_HIP(hipMemcpyAsync(c->h_pf_err, a.err, 16, hipMemcpyDeviceToHost, c->s));
@@ -760,22 +787,22 @@ static int persist_bwd_rows(const nvqa_ctx *c, int *RB)
     return MT;
 }
 
-template <int GK, int MT, int NTN, bool BF>
+template <int GK, int MT, int NTN, bool BF, bool RAG>
 static int launch_persist_bwd(nvqa_ctx *c, const PersistBwdArgs &a, int grid)
 {
     const size_t lds = PersistBwdGeom<MT, NTN>::LDS_BYTES;
     static int resident = -1;
     if (resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_bwd_persist<GK, MT, NTN, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_bwd_persist<GK, MT, NTN, BF, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nb = 0;
-        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_bwd_persist<GK, MT, NTN, BF>, NVQA_PF_THREADS, lds));
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_bwd_persist<GK, MT, NTN, BF, RAG>, NVQA_PF_THREADS, lds));
         resident = nb;
     }
     if (resident < 1 || grid > c->num_cus) {
         set_error("persistent BPTT kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
         return -1;
     }
-    hipLaunchKernelGGL((k_lstm_bwd_persist<GK, MT, NTN, BF>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    hipLaunchKernelGGL((k_lstm_bwd_persist<GK, MT, NTN, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -811,12 +838,13 @@ static int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * R * ((double)(TS - 1) + (l + 1 < L ? TS : 0));
     ProfScope ps(c, PF_LSTM_BWD, flops, 0);
     NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
+    const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform; // as in lstm_forward_persist
     if (c->bf16) {
-        if (L == 1) NVQA_TRY((launch_persist_bwd<16, 4, 2, true>(c, a, grid)));
-        else NVQA_TRY((launch_persist_bwd<16, 4, 4, true>(c, a, grid)));
+        if (L == 1) { if (rag) NVQA_TRY((launch_persist_bwd<16, 4, 2, true, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<16, 4, 2, true, false>(c, a, grid))); }
+        else { if (rag) NVQA_TRY((launch_persist_bwd<16, 4, 4, true, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<16, 4, 4, true, false>(c, a, grid))); }
     } else {
-        if (MT == 4) NVQA_TRY((launch_persist_bwd<32, 4, 2, false>(c, a, grid)));
-        else NVQA_TRY((launch_persist_bwd<32, 7, 2, false>(c, a, grid)));
+        if (MT == 4) { if (rag) NVQA_TRY((launch_persist_bwd<32, 4, 2, false, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<32, 4, 2, false, false>(c, a, grid))); }
+        else { if (rag) NVQA_TRY((launch_persist_bwd<32, 7, 2, false, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<32, 7, 2, false, false>(c, a, grid))); }
     }
     NVQA_HIP(hipMemcpyAsync(c->h_pf_err + 4, a.err, 16, hipMemcpyDeviceToHost, c->s));
     return 0;
@@ -950,6 +978,51 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
     return 0;
 }
 
+// Embedding / lookup-table gradient by token segments (kernels.h: k_tok_index + k_emb_bwd_seg).  The index of the packed
+// token list is built on a side stream as soon as the forward pass has written ptok, under the LSTM unroll.
+static bool emb_index_ok(const nvqa_ctx *c, int VT, int NP)
+{
+    return c->tok_seg && NP <= NVQA_TI_NPT * NVQA_TI_THREADS && VT <= 65535 && tok_index_lds(VT, NP) <= 160 * 1024 && c->d.E <= 512;
+}
+static int emb_index_begin(nvqa_ctx *c, int VT, int NP)
+{
+    if (!emb_index_ok(c, VT, NP)) return 0;
+    // (main stream: the persistent forward kernel holds every CU, a side stream would only run behind it)
+    static bool attr = false;
+    if (!attr) { NVQA_HIP(hipFuncSetAttribute((const void *)k_tok_index, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    ProfScope ps(c, PF_ASSEMBLE, 0, 0);
+    hipLaunchKernelGGL(k_tok_index, dim3(1), dim3(NVQA_TI_THREADS), tok_index_lds(VT, NP), c->s, c->ptok, NP, VT, c->seg_start, c->perm,
+                       c->pslot, c->seg_done, c->pslot + (NP / NVQA_ES_SHORT + 2));
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+// dWeT [VT][E] = sum over the packed positions of each token; plain = 1: nn.LookupTable (arch2), 0: arch1's Tanh + Dropout
+static int emb_backward(nvqa_ctx *c, int VT, int NP, int T, const float *dX, const Drop &dr, float *dWeT, int plain)
+{
+    const nvqa_dims &d = c->d;
+    const int E = d.E, B = d.B;
+    ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * NP * E + (double)VT * E) * 4);
+    if (emb_index_ok(c, VT, NP)) {
+        const int slots = NP / NVQA_ES_SHORT + 2; // c->pslot: [slots] tokens of the long segments, then their number
+        const int32_t *nlong = c->pslot + slots;
+        const dim3 gs((VT + 3) / 4), gl((slots * NVQA_ES_CHUNKS + 3) / 4);
+#define NVQA_ES_GO(NP_)                                                                                                                     \
+    hipLaunchKernelGGL(k_emb_bwd_seg<NP_>, gs, dim3(256), 0, c->s, c->seg_start, c->perm, c->X0, dX, c->sort_idx, B, T, VT, E, dr, dWeT, plain);  \
+    hipLaunchKernelGGL(k_emb_bwd_long<NP_>, gl, dim3(256), 0, c->s, c->seg_start, c->perm, c->pslot, nlong, c->seg_done, c->seg_part,         \
+                       (unsigned)c->seg_part_bytes, c->X0, dX, c->sort_idx, B, T, E, dr, dWeT, plain)
+        if (E <= 256) { NVQA_ES_GO(1); } else { NVQA_ES_GO(2); }
+#undef NVQA_ES_GO
+    } else {
+        const int waves = plain ? 8 : 4; // arch1 tokens spread over the vocabulary: 4 scanning waves (32 KB of LDS, 4 workgroups per CU) beat 8
+        const int blocks = (VT + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
+        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks, (E + NVQA_EB_COLS - 1) / NVQA_EB_COLS), dim3(64 * waves),
+                           (size_t)waves * NVQA_EB_ROWS * NVQA_EB_COLS * sizeof(float), c->s, c->ptok, c->X0, dX, c->sort_idx, NP, B, T, VT, E, dr,
+                           dWeT, plain);
+    }
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // arch1
 // ------------------------------------------------------------------------------------
@@ -969,6 +1042,7 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
                            c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok);
     }
     NVQA_HIP(hipGetLastError());
+    if (train) NVQA_TRY(emb_index_begin(c, d.V, TB));
     NVQA_TRY(lstm_forward(c, dr));
     {
         ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * (Q + I) * 4);
@@ -1057,15 +1131,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     // embedding gradient first, so that its 11.8 MB all-reduce and those of the upper LSTM layers travel
     // under the weight-gradient GEMMs; only layer 0's slice (5.8 MB) is exchanged after the last kernel
     NVQA_TRY(lstm_dx0(c, dX0));
-    {
-        ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)V * E) * 4);
-        const int waves = 4; // arch1 tokens spread over the vocabulary: 4 scanning waves (32 KB of LDS, 4 workgroups per CU) beat 8
-        const int blocks = (V + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
-        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks, (E + NVQA_EB_COLS - 1) / NVQA_EB_COLS), dim3(64 * waves),
-                           (size_t)waves * NVQA_EB_ROWS * NVQA_EB_COLS * sizeof(float), c->s,
-                           c->ptok, c->X0, dX0, c->sort_idx, TB, B, T, V, E, dr, G + c->lo.w_e, 0);
-    }
-    NVQA_HIP(hipGetLastError());
+    NVQA_TRY(emb_backward(c, V, TB, T, dX0, dr, G + c->lo.w_e, 0));
     NVQA_TRY(colsum(c, G + c->lo.w_e, V, E, E, G + c->lo.b_e, nullptr));
     NVQA_TRY(reduce_segment(c, 1)); // embedding
     for (int l = L - 1; l >= 0; --l) NVQA_TRY(lstm_wgrads(c, l)); // + the layer's slice of the encoder segment
@@ -1093,6 +1159,7 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
         hipLaunchKernelGGL(k_arch2_embed, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->tinfo, c->P + c->lo.w_lk, B, T, d.V, E, c->X0, c->ptok);
     }
     NVQA_HIP(hipGetLastError());
+    if (train && !(c->quirks & NVQA_QUIRK_LOOKUP)) NVQA_TRY(emb_index_begin(c, d.V + 1, TB));
     if (c->quirks & NVQA_QUIRK_H0) // top-layer h0 = what the last backward left in the aliased tensor (Encoder_lstm.lua:238-239)
         NVQA_HIP(hipMemcpyAsync(c->Hs[L - 1], c->dHT + (size_t)(L - 1) * B * R, (size_t)B * R * 4, hipMemcpyDeviceToDevice, c->s));
     NVQA_TRY(lstm_forward(c, dr));
@@ -1145,14 +1212,8 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     if (c->quirks & NVQA_QUIRK_LOOKUP) { // the reference's flat gradient never receives the lookup gradient: zeros, nothing to exchange
         NVQA_HIP(hipMemsetAsync(G + c->lo.w_lk, 0, (size_t)(V + 1) * E * 4, c->s));
     } else {   // LookupTable gradient, summed over all steps into the shared gradWeight (Encoder_lstm.lua:53-58,256)
-        ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * TB * E + (double)(V + 1) * E) * 4);
-        const int waves = 8;
-        const int blocks = (V + 1 + NVQA_EB_ROWS - 1) / NVQA_EB_ROWS;
-        hipLaunchKernelGGL(k_emb_bwd, dim3(blocks, (E + NVQA_EB_COLS - 1) / NVQA_EB_COLS), dim3(64 * waves),
-                           (size_t)waves * NVQA_EB_ROWS * NVQA_EB_COLS * sizeof(float), c->s,
-                           c->ptok, c->X0, c->dX0, c->sort_idx, TB, B, TS, V + 1, E, dr, G + c->lo.w_lk, 1);
+        NVQA_TRY(emb_backward(c, V + 1, TB, TS, c->dX0, dr, G + c->lo.w_lk, 1));
     }
-    NVQA_HIP(hipGetLastError());
     if (!(c->quirks & NVQA_QUIRK_LOOKUP))
         NVQA_TRY(reduce_range(c, c->lo.w_lk, (size_t)(V + 1) * E, 1)); // lookup table: travels under the weight-gradient GEMMs
     for (int l = L - 1; l >= 0; --l) NVQA_TRY(lstm_wgrads(c, l));  // + each layer's slice of the encoder segment

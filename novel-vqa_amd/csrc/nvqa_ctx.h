@@ -73,6 +73,14 @@ struct nvqa_ctx {
     int device = 0;
     hipStream_t s = nullptr;                     // compute stream
     hipEvent_t evStart = nullptr;                // hand-off from the extractor's stream (nvqa_step_images)
+    hipStream_t sx = nullptr;                    // side stream: the token-segment index of the embedding gradient, under the forward pass
+    hipEvent_t evTok = nullptr, evIdx = nullptr; // ptok written / index ready
+    bool tok_seg = true;                         // NVQA_EMB_SEG=0: the scanning kernel (k_emb_bwd) instead
+    int32_t *seg_start = nullptr, *pslot = nullptr;
+    uint16_t *perm = nullptr;
+    unsigned *seg_done = nullptr;
+    float *seg_part = nullptr;
+    size_t seg_part_bytes = 0;
     hipStream_t sc = nullptr;                    // communication stream (RCCL all-reduce buckets)
     hipEvent_t evSeg[3 + NVQA_MAX_LAYERS] = {}, evComm = nullptr; // gradient range ready (3 segments + per-layer slices) / exchange done
     int TS = 0; // recurrent steps: arch1 T, arch2 T+2

@@ -112,3 +112,60 @@ def test_evaluate_validation_loss_and_multiple_choice(pkg, orc):
             assert np.array_equal(got[[i for i in range(n) if mc[i].any()]], exp)
             assert all(got[i] == 0 for i in range(n) if not mc[i].any())
         ctx.close()
+
+
+@pytest.mark.parametrize("arch", [1, 2])
+def test_embedding_gradient_skewed_vocabulary(pkg, orc, arch):
+    """Real questions are Zipfian ("what", "is", "the" in most of them; arch2's START token in every row): the embedding /
+    lookup gradient by token segments (kernels.h: k_tok_index + k_emb_bwd_seg) with words that occur once, a few dozen
+    times (one wave), several hundred times and more than B times (chunked over waves, combined by the last to arrive)
+    against the f64 oracle; bit-reproducible; and the same values as the scanning kernel (NVQA_EMB_SEG=0) to f32
+    summation-order noise."""
+    import os
+    from util import assert_grads, gdims, gdrop
+    kw = (dict(arch=1, B=512, T=26, V=14773, E=200, R=64, L=1, I=64, C=64, A=40) if arch == 1 else
+          dict(arch=2, B=512, T=26, V=14773, E=512, R=64, L=1, I=64, C=4, A=40))
+    d = orc.make_dims(**kw)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d, seed=5, full_length=False, min_len=4)
+    rng = np.random.default_rng(17)
+    # Zipf over a 3000-word head + the uniform tail that synth_batch drew; word 7 twice per question where it fits
+    zipf = np.minimum(rng.zipf(1.3, tok.shape), 3000).astype(np.int32)
+    use = rng.random(tok.shape) < 0.7
+    tok = np.where((tok > 0) & use, zipf, tok).astype(np.int32)
+    live = tok > 0
+    for b in range(d.B):
+        idx = np.nonzero(live[b])[0]
+        if len(idx) >= 6:
+            tok[b, idx[1]] = 7
+            tok[b, idx[4]] = 7
+    counts = np.bincount(tok[tok > 0])
+    assert counts.max() > d.B and (counts == 1).sum() > 100 and ((counts > 32) & (counts < 512)).sum() > 3
+    lens_ = lens if arch == 1 else None
+    dr = orc.Dropout(1, 0.5, 123, 3)
+    ref = orc.Oracle(np.float64).step(d, params, tok, lens_, img, lab, dr)
+    got = {}
+    for seg in ("1", "0"):
+        old = os.environ.get("NVQA_EMB_SEG")
+        os.environ["NVQA_EMB_SEG"] = seg
+        try:
+            ctx = pkg.binding.Context(gdims(pkg, d), 0)
+        finally:
+            if old is None:
+                del os.environ["NVQA_EMB_SEG"]
+            else:
+                os.environ["NVQA_EMB_SEG"] = old
+        ctx.set_params(params)
+        loss = ctx.step(tok, lens_, img, lab, gdrop(pkg, dr))
+        g = ctx.get_grads()
+        assert abs(loss - ref["loss"]) <= 2e-6 * abs(ref["loss"])
+        assert_grads(orc, d, g, ref["grads"], 2e-5, f"emb_skew_arch{arch}_seg{seg}")
+        l2 = ctx.step(tok, lens_, img, lab, gdrop(pkg, dr))
+        assert l2 == loss and np.array_equal(ctx.get_grads(), g)
+        got[seg] = g
+        ctx.close()
+    lo = orc.layout(d)
+    o, n = lo["w_e" if arch == 1 else "w_lk"]
+    a, b = got["1"][o:o + n], got["0"][o:o + n]
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+    assert np.count_nonzero(a) > 0
