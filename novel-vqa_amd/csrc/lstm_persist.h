@@ -180,6 +180,20 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     constexpr int NE = (ROWS + 63) / 64;
     const int eq = tid & 3, erow = tid >> 2;
     float cst[NE][4]; // the cell state of the owned (row, unit)s lives in registers across steps
+    auto load_bias = [&](int g) {
+        return *reinterpret_cast<const pf_f32x4 *>(a.bi[l] + g * R + u0 + 4 * eq) + *reinterpret_cast<const pf_f32x4 *>(a.bh[l] + g * R + u0 + 4 * eq);
+    };
+    pf_f32x4 bias_r[BF ? 4 : 1]; // bf16 instance: the packed weights leave room to keep the biases in registers
+    if constexpr (BF) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_r[g] = load_bias(g);
+    }
+    int esi[NE];      // original batch row of the owned rows (the dropout stream is indexed by it): the same at every step
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int grow = rb + RBn * (erow + 64 * e);
+        esi[e] = erow + 64 * e < ROWS && grow < a.B ? a.sort_idx[grow] : 0;
+    }
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
@@ -399,12 +413,11 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         }
         __syncthreads();
         const int nr = a.nrows[t];
-        pf_f32x4 bias[4]; // b_i2h + b_h2h of the owned unit quad (re-read per step: 8 cached loads instead of 16 registers)
+        pf_f32x4 bias[4]; // b_i2h + b_h2h of the owned unit quad (f32: re-read per step, 8 cached loads instead of 16 registers)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const pf_f32x4 x = *reinterpret_cast<const pf_f32x4 *>(a.bi[l] + g * R + u0 + 4 * eq);
-            const pf_f32x4 y = *reinterpret_cast<const pf_f32x4 *>(a.bh[l] + g * R + u0 + 4 * eq);
-            bias[g] = x + y;
+            if constexpr (BF) bias[g] = bias_r[g];
+            else bias[g] = load_bias(g);
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -418,7 +431,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
                 const pf_f32x4 p1 = *reinterpret_cast<const pf_f32x4 *>(&Sg[(row * 4 + 1) * 16 + 4 * eq]);
                 const pf_f32x4 p2 = *reinterpret_cast<const pf_f32x4 *>(&Sg[(row * 4 + 2) * 16 + 4 * eq]);
                 const pf_f32x4 p3 = *reinterpret_cast<const pf_f32x4 *>(&Sg[(row * 4 + 3) * 16 + 4 * eq]);
-                const uint64_t didx = ((((uint64_t)l) * B + a.sort_idx[grow]) * TS + t) * R + u0 + 4 * eq;
+                const uint64_t didx = ((((uint64_t)l) * B + esi[e]) * TS + t) * R + u0 + 4 * eq;
                 if (a.dbg & 16) { // libdevice expf / tanhf (A/B against the hardware forms)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {

@@ -196,6 +196,9 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
 #pragma unroll
         for (int j = 0; j < 4; ++j) dcst[e][j] = v[j];
     }
+    int esi[NE]; // original batch row of the owned rows (indexes the dropout stream): the same at every step
+#pragma unroll
+    for (int e = 0; e < NE; ++e) esi[e] = a.sort_idx[min(rb + RBn * (erow + RPP * e), B - 1)];
     const unsigned crec = (unsigned)((l * RBn + rb) * TS);                 // REC(l) counters of this row block
     const unsigned cneed = (unsigned)((la * RBn + rb) * TS);               // counters of the producers of the A operand
     const unsigned cup = (unsigned)(((l * RBn + rb) * a.NU + ut) * TS);    // UP(l) flag of this tile
@@ -209,7 +212,6 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
         if constexpr (RAG) mt_cur = __builtin_amdgcn_readfirstlane(min(MT, ((nr > rb ? (nr - rb + RBn - 1) / RBn : 0) + 15) >> 4));
         const bool head_now = a.tlast ? (*a.tlast == s) : (s == TS - 1);
         pf_f32x4 e_ig[2], e_fg[2], e_og[2], e_gg[2], e_cc[2], e_cp[2];
-        int e_si[2];
         pf_f32x4 e_v2[NE]; // the UP(l, s) products of the owned cells (another workgroup's bytes: after its flag, sc1 loads)
         auto fetch = [&](int e, int k) { // unconditional, row clamped into the batch
             if (a.dbg & 4) return; // measurement: the cell backward's operands are not loaded
@@ -222,7 +224,6 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             e_gg[k] = *reinterpret_cast<const pf_f32x4 *>(gt + 3 * R);
             e_cc[k] = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + ((size_t)(s + 1) * B + grow) * R + u0 + 4 * eq);
             e_cp[k] = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + srow_g * R + u0 + 4 * eq);
-            e_si[k] = a.sort_idx[grow];
         };
         if (!is_up) {
             fetch(0, 0);
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
                 const pf_f32x4 ig = e_ig[k], fg = e_fg[k], og = e_og[k], gg = e_gg[k], cc = e_cc[k], cp = e_cp[k], v2 = e_v2[e];
                 pf_f32x4 hx = {0.f, 0.f, 0.f, 0.f};
                 if (head_now) hx = *reinterpret_cast<const pf_f32x4 *>(a.dHT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
-                const uint64_t didx = ((((uint64_t)l) * B + e_si[k]) * TS + s) * R + u0 + 4 * eq;
+                const uint64_t didx = ((((uint64_t)l) * B + esi[e]) * TS + s) * R + u0 + 4 * eq;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float dsc = has_up ? a.dr.scale(NVQA_SITE_LSTM, didx + j) : 0.f;
