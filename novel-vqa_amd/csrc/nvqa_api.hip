@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "lstm_persist.h"
 #include "lstm_persist_bwd.h"
+#include "wgrad_bf16.h"
 #include "nvqa_ctx.h"
 
 using namespace nvqa;
@@ -271,6 +272,8 @@ static int create_impl(nvqa_ctx *c)
     { // token-segment index for the embedding gradient (kernels.h: k_tok_index)
         const char *e = getenv("NVQA_EMB_SEG");
         c->tok_seg = !(e && e[0] == '0');
+        e = getenv("NVQA_WGRAD_TR"); // 0: bf16 weight gradients through gemm_f32.h's BF mode (A/B runs)
+        c->wgrad_tr = !(e && e[0] == '0');
         const size_t VT = d.V + 1, slots = TB / NVQA_ES_SHORT + 2;
         NVQA_TRY(dalloc(&c->seg_start, VT + 1));
         NVQA_HIP(hipMemsetAsync(c->seg_start, 0, (VT + 1) * 4, c->s));
@@ -564,11 +567,49 @@ static int colsum(nvqa_ctx *c, const float *X, int M, int N, int ld, float *out,
     return 0;
 }
 
+// bf16 operand mode: the gfx950 k-major kernel (wgrad_bf16.h); A16 / B16: bf16 images of the operands where this step's
+// persistent kernels wrote them (NULL: rounded from the f32 rows on the way into LDS -- the same values either way)
+static int wgrad_bf16(nvqa_ctx *c, const float *A, const unsigned short *A16, int lda, const float *Bm, const unsigned short *B16, int ldb,
+                      int M, int N, int K, float *dW, float *slabs, hipStream_t st)
+{
+    const int tiles = ((M + NVQA_WB_BM - 1) / NVQA_WB_BM) * ((N + NVQA_WB_BN - 1) / NVQA_WB_BN);
+    int ks = 1;
+    while (ks < 16 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2; // tools/kbench15: 2048 x 512: 8 slices, 2048 x 200: 16
+    if ((size_t)ks * M * N > c->slab_floats) ks = std::max<int>(1, (int)(c->slab_floats / ((size_t)M * N)));
+    int kslice = ((K + ks - 1) / ks + NVQA_WB_BK - 1) / NVQA_WB_BK * NVQA_WB_BK;
+    ks = (K + kslice - 1) / kslice;
+    if (M % 8 || lda % 8) A16 = nullptr;
+    if (N % 8 || ldb % 8) B16 = nullptr;
+    {
+        ProfScope ps(c, PF_GEMM_WGRAD, 2.0 * M * N * K, ((double)K * (M + N) * (A16 ? 2 : 4) + (double)ks * M * N * 4), st);
+        WgradBf16Args g{A, Bm, A16, B16, ks == 1 ? dW : slabs, ks == 1 ? 0 : (size_t)M * N, lda, ldb, N, M, N, K, kslice};
+        const dim3 grid((M + NVQA_WB_BM - 1) / NVQA_WB_BM, (N + NVQA_WB_BN - 1) / NVQA_WB_BN, ks);
+        static bool attr = false;
+        if (!attr) {
+            NVQA_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NVQA_WB_LDS_BYTES));
+            NVQA_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NVQA_WB_LDS_BYTES));
+            NVQA_HIP(hipFuncSetAttribute((const void *)k_wgrad_bf16<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NVQA_WB_LDS_BYTES));
+            attr = true;
+        }
+        if (A16 && B16) hipLaunchKernelGGL((k_wgrad_bf16<true, true>), grid, dim3(256), NVQA_WB_LDS_BYTES, st, g);
+        else if (A16) hipLaunchKernelGGL((k_wgrad_bf16<true, false>), grid, dim3(256), NVQA_WB_LDS_BYTES, st, g);
+        else hipLaunchKernelGGL((k_wgrad_bf16<false, false>), grid, dim3(256), NVQA_WB_LDS_BYTES, st, g);
+        NVQA_HIP(hipGetLastError());
+    }
+    if (ks == 1) return 0;
+    ProfScope ps(c, PF_REDUCE, 0, (double)(ks + 1) * M * N * 4, st);
+    const size_t n4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n4 + 255) / 256), dim3(256), 0, st, slabs, ks, n4, reinterpret_cast<float4 *>(dW));
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
 // dW[M x N] = A^T B with A stored [K][M], B stored [K][N]; K = TS*B is long, the output
 // small: split K over blockIdx.z into slabs, then sum the slabs in order (deterministic).
 static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb, int M, int N, int K,
-                 float *dW, float *slabs, hipStream_t st)
+                 float *dW, float *slabs, hipStream_t st, const unsigned short *A16 = nullptr, const unsigned short *B16 = nullptr)
 {
+    if (c->bf16 && c->wgrad_tr && M % 4 == 0 && N % 4 == 0) return wgrad_bf16(c, A, A16, lda, Bm, B16, ldb, M, N, K, dW, slabs, st);
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int ks = 1;
     while (ks < 16 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2; // tools/kbench11: 2048 x 200 x 13312: 16 slices 115 us, 8 slices 129 us
@@ -701,7 +742,8 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
-    if (const int MT = persist_rows(c)) return lstm_forward_persist(c, dr, MT);
+    c->img_fwd_valid = c->img_bwd_valid = false;
+    if (const int MT = persist_rows(c)) { c->img_fwd_valid = c->bf16; return lstm_forward_persist(c, dr, MT); }
     // Layer 0 takes W_i2h x_t as a first K segment inside the level kernel, like the layers above it: the
     // time-batched projection (0.128 ms, a 109 MB write and its re-read by the level epilogues) costs more than
     // the 0.074 ms the extra K = E adds to the 27 levels, and the two layers' workgroups become closer in length
@@ -856,7 +898,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
     {
         int RB = 0;
-        if (const int MT = persist_bwd_rows(c, &RB)) return lstm_backward_persist(c, dr, MT, RB);
+        if (const int MT = persist_bwd_rows(c, &RB)) { c->img_bwd_valid = c->bf16; return lstm_backward_persist(c, dr, MT, RB); }
     }
     const bool ring = c->use_ring && !c->bf16;
     const size_t wt = (size_t)4 * R * R;
@@ -951,8 +993,13 @@ static int lstm_wgrads(nvqa_ctx *c, int l)
     const int R = d.R, TB = c->TS * d.B;
     const int in = l == 0 ? d.E : R;
     const float *Xin = l == 0 ? c->X0 : c->U[l];
-    NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s));
-    NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s));
+    // bf16 images of the operands, where this step's persistent bf16 kernels left them (lstm_persist.h / lstm_persist_bwd.h)
+    const size_t hs = (size_t)(c->TS + 1) * d.B * R, us = (size_t)c->TS * d.B * R;
+    const unsigned short *G16 = c->img_bwd_valid ? c->dg_b16 + (size_t)l * TB * 4 * R : nullptr;
+    const unsigned short *H16 = c->img_fwd_valid ? c->act_b16 + l * hs : nullptr;
+    const unsigned short *X16 = c->img_fwd_valid && l > 0 ? c->act_b16 + d.L * hs + l * us : nullptr;
+    NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s, G16, H16));
+    NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s, G16, X16));
     NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
     NVQA_TRY(reduce_range(c, c->lo.w_i2h[l], c->lo.b_h2h[l] + 4 * (size_t)R - c->lo.w_i2h[l], 3 + l));
     return 0;

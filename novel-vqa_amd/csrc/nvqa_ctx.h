@@ -121,6 +121,8 @@ struct nvqa_ctx {
     unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed before every launch)
     size_t pf_cnt_words = 0;
     unsigned long long *pf_ts = nullptr; // debug timestamps of the persistent kernels (NVQA_PF_DBG & 32)
+    bool img_fwd_valid = false, img_bwd_valid = false; // this step's persistent bf16 kernels wrote act_b16 / dg_b16
+    bool wgrad_tr = true;              // bf16 weight gradients on the transposed-read kernel (wgrad_bf16.h)
     unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd.h)
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the err records (forward: words 0-3, BPTT: words 4-7)
