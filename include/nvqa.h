@@ -137,9 +137,13 @@ int nvqa_evaluate(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t
 int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
 
 /* ---- model variants of the reference's other training scripts -------------- */
-/* askip = 1: netdef.AskipB fusion, output = qc + qc (*) ic (misc/netdef.lua:16-25,
- * 003_train_ae_based_wp.lua:151) instead of netdef.AxB.  arch1 only. */
-int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
+/* The fusion module in front of the classifier (002_train_vqa_arch1/misc/netdef.lua), arch1 only:
+ *   mode 0  netdef.AxB    (:6-14)   qc (*) ic                      -- what every training script of the reference uses
+ *   mode 1  netdef.AskipB (:16-25)  qc + qc (*) ic                 -- 003_train_ae_based_wp.lua:151
+ *   mode 2  netdef.A_B    (:27-35)  JoinTable(2)({qc, ic}): the classifier reads 2C values, so W_o becomes [A x 2C]:
+ *           nvqa_param_count / nvqa_segments / include/nvqa_layout.h (nvqa_layout_init_fusion) change.  Switching to or
+ *           from mode 2 is only accepted on a context that has not been given parameters yet (right after nvqa_create). */
+int nvqa_set_fusion(nvqa_ctx *ctx, int mode);
 /* BASELINE config "arch2 ... bf16": bf16 = 1 runs every dense product of the step (forward, dgrad, wgrad)
  * on the bf16 matrix cores: both operands rounded to bf16 (round-to-nearest-even) as they are read,
  * products accumulated in f32.  Parameters, activations, gradients, the optimiser and everything at this

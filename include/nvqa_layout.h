@@ -32,7 +32,9 @@ typedef struct nvqa_layout {
     size_t w_lk;     /* lookup table [(V+1) x E] */
 } nvqa_layout;
 
-static inline int nvqa_layout_init(const nvqa_dims *d, nvqa_layout *lo)
+/* fusion: 0 netdef.AxB / 1 netdef.AskipB: the classifier reads the C-wide product; 2 netdef.A_B (misc/netdef.lua:27-35):
+ * it reads JoinTable(qc, ic), 2C wide, so W_o is [A x 2C] (arch1 only) */
+static inline int nvqa_layout_init_fusion(const nvqa_dims *d, int fusion, nvqa_layout *lo)
 {
     size_t off = 0;
     const size_t R = (size_t)d->R, E = (size_t)d->E, V = (size_t)d->V, I = (size_t)d->I;
@@ -58,7 +60,7 @@ static inline int nvqa_layout_init(const nvqa_dims *d, nvqa_layout *lo)
         lo->b_q = off; off += C;
         lo->w_v = off; off += C * I;
         lo->b_v = off; off += C;
-        lo->w_o = off; off += A * C;
+        lo->w_o = off; off += A * (fusion == 2 ? 2 * C : C);
         lo->b_o = off; off += A;
         lo->seg[2] = off - lo->seg[0] - lo->seg[1];
         lo->w_p = lo->b_p = lo->w_lk = 0;
@@ -89,5 +91,6 @@ static inline int nvqa_layout_init(const nvqa_dims *d, nvqa_layout *lo)
     lo->total = off;
     return 0;
 }
+static inline int nvqa_layout_init(const nvqa_dims *d, nvqa_layout *lo) { return nvqa_layout_init_fusion(d, 0, lo); }
 
 #endif /* NVQA_LAYOUT_H */

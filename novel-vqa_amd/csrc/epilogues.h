@@ -67,6 +67,12 @@ struct EpiFuse {
         const size_t o = (size_t)m * ldc + n;
         const float i = tanhf_(v + b[n]);
         ic[o] = i;
+        if (askip == 2) { // netdef.A_B: zd = Dropout([qc | ic]), 2 ldc wide
+            const size_t z = (size_t)m * 2 * ldc + n;
+            zd[z] = dr.scale(NVQA_SITE_Z, z) * qc[o];
+            zd[z + ldc] = dr.scale(NVQA_SITE_Z, z + ldc) * i;
+            return;
+        }
         zd[o] = dr.scale(NVQA_SITE_Z, o) * (askip ? qc[o] + qc[o] * i : qc[o] * i);
     }
 };
@@ -80,6 +86,12 @@ struct EpiHeadBwd {
     int askip;
     __device__ __forceinline__ void operator()(int, int m, int n, float v) const
     {
+        if (askip == 2) { // netdef.A_B: v = d(zd)[m][n], n < 2 ldc: the qc half, then the ic half
+            const float dz = dr.scale(NVQA_SITE_Z, (size_t)m * 2 * ldc + n) * v;
+            if (n < ldc) { const float q = qc[(size_t)m * ldc + n]; dqc[(size_t)m * ldc + n] = dz * (1.0f - q * q); }
+            else { const float i = ic[(size_t)m * ldc + n - ldc]; dic[(size_t)m * ldc + n - ldc] = dz * (1.0f - i * i); }
+            return;
+        }
         const size_t o = (size_t)m * ldc + n;
         const float dz = dr.scale(NVQA_SITE_Z, o) * v;
         const float q = qc[o], i = ic[o];

@@ -739,6 +739,12 @@ __global__ void k_head_fuse(const float *sq, const float *sv, int Z, size_t n, i
     const float q = tanhf_(a + bq[c]), v = tanhf_(b + bv[c]);
     qc[i] = q;
     ic[i] = v;
+    if (askip == 2) { // netdef.A_B: zd = Dropout([qc | ic]), 2C wide
+        const size_t b = i / C, o = b * 2 * C + c;
+        zd[o] = dr.scale(NVQA_SITE_Z, o) * q;
+        zd[o + C] = dr.scale(NVQA_SITE_Z, o + C) * v;
+        return;
+    }
     zd[i] = dr.scale(NVQA_SITE_Z, i) * (askip ? q + q * v : q * v); // netdef.AskipB : netdef.AxB
 }
 

@@ -253,12 +253,15 @@ static int create_impl(nvqa_ctx *c)
         NVQA_HIP(hipEventCreateWithFlags(&c->evComm, hipEventDisableTiming));
         NVQA_HIP(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
     }
-    NVQA_TRY(dalloc(&c->P, c->lo.total));
-    NVQA_TRY(dalloc(&c->G, c->lo.total));
-    NVQA_TRY(dalloc(&c->M2, c->lo.total));
-    NVQA_HIP(hipMemsetAsync(c->P, 0, c->lo.total * 4, c->s));
-    NVQA_HIP(hipMemsetAsync(c->G, 0, c->lo.total * 4, c->s));
-    NVQA_HIP(hipMemsetAsync(c->M2, 0, c->lo.total * 4, c->s));
+    // (sized for the widest layout of these dimensions: nvqa_set_fusion(ctx, 2) = netdef.A_B makes W_o [A x 2C])
+    size_t total_max = c->lo.total;
+    if (d.arch == NVQA_ARCH1) { nvqa_layout lj; if (!nvqa_layout_init_fusion(&c->d, 2, &lj)) total_max = std::max(total_max, lj.total); }
+    NVQA_TRY(dalloc(&c->P, total_max));
+    NVQA_TRY(dalloc(&c->G, total_max));
+    NVQA_TRY(dalloc(&c->M2, total_max));
+    NVQA_HIP(hipMemsetAsync(c->P, 0, total_max * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->G, 0, total_max * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->M2, 0, total_max * 4, c->s));
     NVQA_TRY(dalloc(&c->tok, B * d.T));
     NVQA_TRY(dalloc(&c->len, B));
     NVQA_TRY(dalloc(&c->lab, B));
@@ -307,7 +310,7 @@ static int create_impl(nvqa_ctx *c)
     NVQA_TRY(dalloc(&c->vd, B * d.I));
     NVQA_TRY(dalloc(&c->qc, B * C));
     NVQA_TRY(dalloc(&c->ic, B * C));
-    NVQA_TRY(dalloc(&c->zd, B * C));
+    NVQA_TRY(dalloc(&c->zd, B * 2 * C)); // 2C: netdef.A_B joins qc and ic
     NVQA_TRY(dalloc(&c->dqc, B * std::max(C, R)));
     NVQA_TRY(dalloc(&c->dic, B * C));
     NVQA_TRY(dalloc(&c->scores, B * d.A));
@@ -488,6 +491,7 @@ static void to_abi(const nvqa_ctx *c, const std::vector<float> &in, float *abi)
 
 extern "C" int nvqa_set_params(nvqa_ctx *c, const float *params)
 {
+    if (c) c->pristine = false;
     if (!c || !params) { set_error("NULL argument"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     std::vector<float> in;
@@ -510,6 +514,7 @@ extern "C" int nvqa_get_params(nvqa_ctx *c, float *out)
 
 extern "C" int nvqa_init_params(nvqa_ctx *c, uint64_t seed, float lo, float hi)
 {
+    if (c) c->pristine = false;
     if (!c) { set_error("ctx is NULL"); return -1; }
     // *_w:uniform(-0.08, 0.08) over each flat segment (002_train_baseline.lua:174-181);
     // counter-based so that every rank of a data-parallel job draws the same values.
@@ -1121,8 +1126,9 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I),
                                            EpiFuse{c->ic, c->zd, c->qc, c->P + c->lo.b_v, C, dr, c->fusion_askip})));
         }
-        // scores = W_o zd + b_o
-        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->zd, C, c->P + c->lo.w_o, C, B, A, C),
+        // scores = W_o zd + b_o (zd: C wide, or [qc | ic] = 2C wide for netdef.A_B)
+        const int ZW = c->fusion_askip == 2 ? 2 * C : C;
+        NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->zd, ZW, c->P + c->lo.w_o, ZW, B, A, ZW),
                                        EpiBias2{c->scores, A, c->P + c->lo.b_o, nullptr})));
     }
     {
@@ -1147,8 +1153,9 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
                      2.0 * B * (2.0 * A * C + 2.0 * C * Q + (double)C * I),
                      (2.0 * A * C + 2.0 * C * Q + 2.0 * C * I) * 4);
         // classifier: dW_o = dscores^T zd ; d(zd) = dscores W_o -> Dropout', CMul', Tanh'
-        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, C, A, C, B), EpiStore{G + c->lo.w_o, C, 0})));
-        NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, C, B, C, A),
+        const int ZW = c->fusion_askip == 2 ? 2 * C : C;
+        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0})));
+        NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, ZW, B, ZW, A),
                                        EpiHeadBwd{c->dqc, c->dic, c->qc, c->ic, C, dr, c->fusion_askip})));
         // fusion: dW_q = dqc^T qd ; dW_v = dic^T vd ; d(qd) = dqc W_q (no gradient to the image)
         NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dqc, C, c->qd, Q, C, Q, B), EpiStore{G + c->lo.w_q, Q, 0})));
@@ -1434,7 +1441,13 @@ extern "C" int nvqa_evaluate(nvqa_ctx *c, int32_t n, const int32_t *tokens, cons
 // model variants of the reference's other training scripts
 extern "C" int nvqa_set_fusion(nvqa_ctx *c, int askip)
 {
-    if (!c || c->d.arch != NVQA_ARCH1 || (askip != 0 && askip != 1)) { set_error("nvqa_set_fusion: arch1 context and mode 0/1 expected"); return -1; }
+    if (!c || c->d.arch != NVQA_ARCH1 || askip < 0 || askip > 2) { set_error("nvqa_set_fusion: arch1 context and mode 0 (AxB) / 1 (AskipB) / 2 (A_B) expected"); return -1; }
+    if ((askip == 2) != (c->fusion_askip == 2)) {
+        // netdef.A_B changes the classifier to Linear(2C, A): another parameter vector.  Only on a context that holds no
+        // parameters, gradients or optimiser state yet (the buffers are sized for either layout at nvqa_create).
+        if (!c->pristine) { set_error("nvqa_set_fusion: switching to / from netdef.A_B changes the parameter layout; call it right after nvqa_create"); return -1; }
+        if (nvqa_layout_init_fusion(&c->d, askip, &c->lo)) { set_error("layout"); return -1; }
+    }
     c->fusion_askip = askip;
     return 0;
 }

@@ -90,7 +90,8 @@ struct nvqa_ctx {
     float *P = nullptr, *G = nullptr, *M2 = nullptr;
     bool have_grads = false;
     int quirks = 0;                   // nvqa_set_ref_quirks (arch2)
-    int fusion_askip = 0;             // 0 netdef.AxB, 1 netdef.AskipB
+    int fusion_askip = 0;             // 0 netdef.AxB, 1 netdef.AskipB, 2 netdef.A_B (W_o [A x 2C])
+    bool pristine = true;             // no parameters set yet: the layout may still change (nvqa_set_fusion)
     float gscale[3] = {1.f, 1.f, 1.f}; // per-segment gradient scale before the clamp (-lr_scale)
 
     // current batch

@@ -239,8 +239,9 @@ class Context:
     def rmsprop_update(self, lr, alpha=0.99, eps=1e-8, wd=0.0, clamp=10.0):
         self._check(self.lib.nvqa_rmsprop_update(self._h, lr, alpha, eps, wd, clamp))
 
-    def set_fusion(self, askip):
-        self._check(self.lib.nvqa_set_fusion(self._h, int(askip)))
+    def set_fusion(self, mode):
+        """0 netdef.AxB, 1 netdef.AskipB, 2 netdef.A_B (W_o becomes [A x 2C]: right after creation only)."""
+        self._check(self.lib.nvqa_set_fusion(self._h, int(mode)))
 
     QUIRK_H0, QUIRK_LOOKUP = 1, 2
 

@@ -32,7 +32,7 @@ int nvqa_evaluate(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t
                   const int32_t *labels, const int32_t *mc_ans, int32_t n_mc, float *scores_out,
                   int32_t *argmax_out, int32_t *mc_argmax_out, float *loss_out);
 int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float wd, float clamp);
-int nvqa_set_fusion(nvqa_ctx *ctx, int askip);
+int nvqa_set_fusion(nvqa_ctx *ctx, int mode);
 int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
 int nvqa_set_ref_quirks(nvqa_ctx *ctx, int flags);
 int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);

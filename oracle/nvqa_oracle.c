@@ -227,7 +227,7 @@ int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok
                       real *scores_out, int32_t *argmax_out)
 {
     nvqa_layout lo;
-    if (d->arch != NVQA_ARCH1 || nvqa_layout_init(d, &lo)) return -1;
+    if (d->arch != NVQA_ARCH1 || nvqa_layout_init_fusion(d, g_fusion_askip, &lo)) return -1;
     const int B = d->B, T = d->T, V = d->V, E = d->E, R = d->R, L = d->L, I = d->I, C = d->C,
               A = d->A;
     const int Q = 2 * R * L;
@@ -331,18 +331,31 @@ int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok
         Dv[z] = drop_scale(dr, NVQA_SITE_V, z);
         vd[z] = Dv[z] * img[z];
     }
-    real *qc = zalloc((size_t)B * C), *ic = zalloc((size_t)B * C), *zd = zalloc((size_t)B * C),
-         *Dz = zalloc((size_t)B * C);
+    /* ZW: width of what the classifier reads: C, or 2C for netdef.A_B = JoinTable(2)({qc, ic}) (netdef.lua:27-35) */
+    const int join = g_fusion_askip == 2, ZW = join ? 2 * C : C;
+    real *qc = zalloc((size_t)B * C), *ic = zalloc((size_t)B * C), *zd = zalloc((size_t)B * ZW),
+         *Dz = zalloc((size_t)B * ZW);
     lin_fwd(B, C, Q, qd, params + lo.w_q, params + lo.b_q, qc);
     lin_fwd(B, C, I, vd, params + lo.w_v, params + lo.b_v, ic);
     for (size_t z = 0; z < (size_t)B * C; ++z) {
         qc[z] = (real)tanh((double)qc[z]);
         ic[z] = (real)tanh((double)ic[z]);
-        Dz[z] = drop_scale(dr, NVQA_SITE_Z, z);
-        zd[z] = Dz[z] * (g_fusion_askip ? qc[z] + qc[z] * ic[z] : qc[z] * ic[z]);
+    }
+    if (join) {
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < ZW; ++j) {
+                const size_t z = (size_t)b * ZW + j; /* the Dropout after the fusion module sees the joined [B x 2C] tensor */
+                Dz[z] = drop_scale(dr, NVQA_SITE_Z, z);
+                zd[z] = Dz[z] * (j < C ? qc[(size_t)b * C + j] : ic[(size_t)b * C + j - C]);
+            }
+    } else {
+        for (size_t z = 0; z < (size_t)B * C; ++z) {
+            Dz[z] = drop_scale(dr, NVQA_SITE_Z, z);
+            zd[z] = Dz[z] * (g_fusion_askip ? qc[z] + qc[z] * ic[z] : qc[z] * ic[z]);
+        }
     }
     real *scores = zalloc((size_t)B * A), *dscores = zalloc((size_t)B * A);
-    lin_fwd(B, A, C, zd, params + lo.w_o, params + lo.b_o, scores);
+    lin_fwd(B, A, ZW, zd, params + lo.w_o, params + lo.b_o, scores);
     const real loss = softmax_ce(B, A, scores, labels, (train && labels) ? dscores : NULL, argmax_out);
     if (loss_out) *loss_out = loss;
     if (scores_out) memcpy(scores_out, scores, sizeof(real) * (size_t)B * A);
@@ -350,13 +363,22 @@ int oracle_arch1_step(const nvqa_dims *d, const real *params, const int32_t *tok
     if (train && grads && labels) {
         memset(grads, 0, sizeof(real) * lo.total);
         /* ---- multimodal backward (002_train_baseline.lua:312) ---- */
-        real *dzd = zalloc((size_t)B * C), *dqc = zalloc((size_t)B * C), *dic = zalloc((size_t)B * C);
-        lin_bwd_dw(B, A, C, dscores, zd, grads + lo.w_o, grads + lo.b_o);
-        lin_bwd_dx(B, A, C, dscores, params + lo.w_o, dzd, 0);
-        for (size_t z = 0; z < (size_t)B * C; ++z) {
-            const real dz = Dz[z] * dzd[z];
-            dqc[z] = dz * (g_fusion_askip ? (real)1 + ic[z] : ic[z]) * ((real)1 - qc[z] * qc[z]);
-            dic[z] = dz * qc[z] * ((real)1 - ic[z] * ic[z]);
+        real *dzd = zalloc((size_t)B * ZW), *dqc = zalloc((size_t)B * C), *dic = zalloc((size_t)B * C);
+        lin_bwd_dw(B, A, ZW, dscores, zd, grads + lo.w_o, grads + lo.b_o);
+        lin_bwd_dx(B, A, ZW, dscores, params + lo.w_o, dzd, 0);
+        if (join) {
+            for (int b = 0; b < B; ++b)
+                for (int j = 0; j < C; ++j) {
+                    const size_t z = (size_t)b * C + j, zq = (size_t)b * ZW + j, zi = zq + C;
+                    dqc[z] = Dz[zq] * dzd[zq] * ((real)1 - qc[z] * qc[z]);
+                    dic[z] = Dz[zi] * dzd[zi] * ((real)1 - ic[z] * ic[z]);
+                }
+        } else {
+            for (size_t z = 0; z < (size_t)B * C; ++z) {
+                const real dz = Dz[z] * dzd[z];
+                dqc[z] = dz * (g_fusion_askip ? (real)1 + ic[z] : ic[z]) * ((real)1 - qc[z] * qc[z]);
+                dic[z] = dz * qc[z] * ((real)1 - ic[z] * ic[z]);
+            }
         }
         lin_bwd_dw(B, C, Q, dqc, qd, grads + lo.w_q, grads + lo.b_q);
         lin_bwd_dw(B, C, I, dic, vd, grads + lo.w_v, grads + lo.b_v);

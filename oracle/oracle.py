@@ -45,8 +45,8 @@ def build(force=False):
     return libs
 
 
-def layout(dims):
-    """Offsets inside the flat parameter vector; mirrors include/nvqa_layout.h."""
+def layout(dims, fusion=0):
+    """Offsets inside the flat parameter vector; mirrors include/nvqa_layout.h (fusion 2 = netdef.A_B: W_o is [A x 2C])."""
     d = dims
     off = 0
     lo = {}
@@ -74,7 +74,7 @@ def layout(dims):
         take("b_q", d.C)
         take("w_v", d.C * d.I)
         take("b_v", d.C)
-        take("w_o", d.A * d.C)
+        take("w_o", d.A * (2 * d.C if fusion == 2 else d.C))
         take("b_o", d.A)
         lo["_segments"] = (s0, s1 - s0, off - s1)
     else:
@@ -103,6 +103,7 @@ class Oracle:
         self.real_p = ctypes.POINTER(ctypes.c_float if self.dtype == np.float32 else ctypes.c_double)
         self.real_t = ctypes.c_float if self.dtype == np.float32 else ctypes.c_double
         self.threads = threads
+        self.fusion = 0
 
     def _p(self, a):
         return None if a is None else a.ctypes.data_as(self.real_p)
@@ -114,7 +115,7 @@ class Oracle:
     def step(self, dims, params, tokens, lengths, img, labels, dropout=None, train=True,
              want_grads=True):
         """Returns dict(loss, grads (unclamped, flat), scores [B,A], argmax [B] 1-based)."""
-        lo = layout(dims)
+        lo = layout(dims, self.fusion if dims.arch == 1 else 0)
         params = np.ascontiguousarray(params, self.dtype)
         assert params.size == lo["_total"], (params.size, lo["_total"])
         tokens = np.ascontiguousarray(tokens, np.int32).reshape(dims.B, dims.T)
@@ -140,9 +141,11 @@ class Oracle:
             raise RuntimeError(f"oracle step failed rc={rc}")
         return {"loss": float(loss.value), "grads": grads, "scores": scores, "argmax": argmax}
 
-    def set_fusion(self, askip):
-        """0 = netdef.AxB, 1 = netdef.AskipB (process-wide switch of the oracle library)."""
-        self.lib.oracle_set_fusion(int(askip))
+    def set_fusion(self, mode):
+        """0 = netdef.AxB, 1 = netdef.AskipB, 2 = netdef.A_B (JoinTable: the classifier becomes Linear(2C, A); use
+        layout(dims, 2) / synth_params(dims, fusion=2)).  Process-wide switch of the oracle library."""
+        self.lib.oracle_set_fusion(int(mode))
+        self.fusion = int(mode)
 
     QUIRK_H0, QUIRK_LOOKUP = 1, 2
 
@@ -179,9 +182,9 @@ class Oracle:
 # tokens uniform in [1,V], image features |N(0,1)| row-L2-normalised,
 # labels uniform in [1,A], params uniform(-0.08, 0.08), seed 123.
 # ----------------------------------------------------------------------------
-def synth_params(dims, seed=123, lo=-0.08, hi=0.08):
+def synth_params(dims, seed=123, lo=-0.08, hi=0.08, fusion=0):
     rng = np.random.default_rng(seed)
-    return rng.uniform(lo, hi, layout(dims)["_total"]).astype(np.float32)
+    return rng.uniform(lo, hi, layout(dims, fusion)["_total"]).astype(np.float32)
 
 
 def right_align(seq, lengths):

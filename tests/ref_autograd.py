@@ -114,12 +114,14 @@ def arch1(dims, lo, params_np, tokens, lengths, img, labels, dr=None, train=True
     Q = 2 * R * L
     Dq = drop_scales(drr, 2, (B, Q), lambda b, j: b * Q + j)
     Dv = drop_scales(drr, 3, (B, I), lambda b, j: b * I + j)
-    Dz = drop_scales(drr, 4, (B, C), lambda b, j: b * C + j)
+    join = askip == 2  # netdef.A_B (misc/netdef.lua:27-35): JoinTable(2)({qc, ic}), classifier Linear(2C, A)
+    ZW = 2 * C if join else C
+    Dz = drop_scales(drr, 4, (B, ZW), lambda b, j: b * ZW + j)
     v = torch.tensor(np.asarray(img, np.float64).reshape(B, I))
     qc = torch.tanh(lin(Dq * q, p["w_q"].view(C, Q), p["b_q"]))
     ic = torch.tanh(lin(Dv * v, p["w_v"].view(C, I), p["b_v"]))
-    fused = qc + qc * ic if askip else qc * ic  # netdef.AskipB / netdef.AxB
-    scores = lin(Dz * fused, p["w_o"].view(A, C), p["b_o"])
+    fused = torch.cat([qc, ic], 1) if join else (qc + qc * ic if askip else qc * ic)  # netdef.A_B / AskipB / AxB
+    scores = lin(Dz * fused, p["w_o"].view(A, ZW), p["b_o"])
     y = torch.tensor(np.asarray(labels, np.int64) - 1)
     loss = torch.nn.functional.cross_entropy(scores, y, reduction="mean")
     grads = None

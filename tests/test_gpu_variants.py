@@ -32,6 +32,46 @@ def test_askipb_fusion(pkg, orc):
     ctx.close()
 
 
+def test_a_b_join_fusion(pkg, orc):
+    """netdef.A_B (misc/netdef.lua:27-35; defined, not called by any reference script): JoinTable(2)({qc, ic}) in front
+    of a Linear(2C, A) classifier = nvqa_set_fusion(ctx, 2).  Another parameter layout (W_o [A x 2C]): accepted only on
+    a fresh context; loss, logits and every gradient segment against the f64 oracle (pinned on the CPU against the
+    independent autograd model, tests/test_oracle.py), through both head routes (split-K slabs + k_head_fuse for the
+    full-size head, the fused epilogue for this small one)."""
+    from util import assert_logits
+    for kw in (KW, dict(arch=1, B=512, T=6, V=50, E=16, R=32, L=1, I=128, C=256, A=40)):
+        d = orc.make_dims(**kw)
+        lo = orc.layout(d, 2)
+        params = orc.synth_params(d, fusion=2)
+        tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+        dr = orc.Dropout(1, 0.5, 123, 2)
+        o = orc.Oracle(np.float64)
+        o.set_fusion(2)
+        try:
+            ref = o.step(d, params, tok, lens, img, lab, dr)
+            ev = o.step(d, params, tok, lens, img, lab, None, train=False)
+        finally:
+            o.set_fusion(0)
+        ctx = pkg.binding.Context(gdims(pkg, d), 0)
+        n0 = ctx.param_count
+        ctx.set_fusion(2)
+        assert ctx.param_count == lo["_total"] == n0 + d.A * d.C
+        ctx.set_params(params)
+        with pytest.raises(pkg.binding.NvqaError):
+            ctx.set_fusion(0)  # the layout is fixed once the context holds parameters
+        loss = ctx.step(tok, lens, img, lab, gdrop(pkg, dr))
+        assert abs(loss - ref["loss"]) <= 2e-6 * abs(ref["loss"])
+        errs = segment_errors(orc, d, ctx.get_grads(), ref["grads"], fusion=2)
+        assert max(errs.values()) < 2e-5, errs
+        scores, argmax = ctx.forward(tok, lens, img)
+        assert_logits(scores, ev["scores"])
+        # the optimiser walks the longer vector too
+        ctx.rmsprop_update(3e-4)
+        p1 = ctx.get_params()
+        assert p1.size == lo["_total"] and np.abs(p1[lo["w_o"][0]:lo["w_o"][0] + lo["w_o"][1]] - params[lo["w_o"][0]:lo["w_o"][0] + lo["w_o"][1]]).max() > 0
+        ctx.close()
+
+
 def test_lr_scale(pkg, orc):
     # gradients = join{enc*lr_scale, emb*lr_scale, mm}; clamp  (003_train_ae_based_wp.lua:344-345)
     d = orc.make_dims(**KW)

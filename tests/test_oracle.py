@@ -38,6 +38,34 @@ def test_oracle_matches_independent_autograd(orc, arch, mode):
     assert relmax(r32["grads"], ref["grads"]) < 1e-5
 
 
+@pytest.mark.parametrize("fusion", [1, 2])
+def test_fusion_variants_match_independent_autograd(orc, fusion):
+    """netdef.AskipB (misc/netdef.lua:16-25) and netdef.A_B (:27-35: JoinTable, classifier Linear(2C, A)) against the
+    independent autograd statement, dropout on; A_B has its own parameter layout (oracle.layout(d, 2))."""
+    d = orc.make_dims(arch=1, **TINY)
+    lo = orc.layout(d, fusion)
+    assert lo["w_o"][1] == d.A * d.C * (2 if fusion == 2 else 1)
+    params = orc.synth_params(d, fusion=fusion)
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    dr = orc.Dropout(1, 0.5, 123, 7)
+    ref = ra.arch1(d, lo, params, tok, lens, img, lab, dr, askip=fusion)
+    base = ra.arch1(d, orc.layout(d), params[:orc.layout(d)["_total"]], tok, lens, img, lab, dr)
+    assert abs(ref["loss"] - base["loss"]) > 1e-6  # the variant is another model
+    o64, o32 = orc.Oracle(np.float64), orc.Oracle(np.float32)
+    try:
+        o64.set_fusion(fusion)
+        r64 = o64.step(d, params, tok, lens, img, lab, dr)
+        o32.set_fusion(fusion)
+        r32 = o32.step(d, params, tok, lens, img, lab, dr)
+    finally:
+        o64.set_fusion(0)
+        o32.set_fusion(0)
+    assert abs(r64["loss"] - ref["loss"]) < 1e-12
+    assert relmax(r64["scores"], ref["scores"]) < 1e-12
+    assert relmax(r64["grads"], ref["grads"]) < 1e-12
+    assert relmax(r32["grads"], ref["grads"]) < 1e-5
+
+
 @pytest.mark.parametrize("arch", [1, 2])
 def test_finite_differences(orc, arch):
     d, params, (tok, lens, img, lab) = _setup(orc, arch)

@@ -17,8 +17,8 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def segment_errors(orc, d, got, ref):
-    lo = orc.layout(d)
+def segment_errors(orc, d, got, ref, fusion=0):
+    lo = orc.layout(d, fusion)
     out = {}
     for k, v in lo.items():
         if k.startswith("_"):
