@@ -649,6 +649,18 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
             for (int tb = 0; tb < NTN; ++tb) asm volatile("" ::"v"(acc[ta][tb]));
         return;
     }
+    // tile-native epilogue (EpiTraits::vec4, MF = 16, WK = 1): the lane's 4 accumulator registers of an MFMA tile go out
+    // as ONE 16-byte store into a slab whose element order is private to the producer and its consumer
+    // (lstm_bwd_level.h): slot = ((wave * NTM + ta) * NTN + tb) * 64 + lane
+    if constexpr (EpiTraits<Epi>::vec4) {
+        static_assert(MF == 16 && WK == 1 && !GATES && SEG == 0, "vec4 epilogue: 16x16 MFMA tiles, no K-group split");
+        const unsigned tile = by * ((g.N + BN - 1) / BN) + bx;
+#pragma unroll
+        for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NTN; ++tb) epi.store4(z, tile, ((wrem * NTM + ta) * NTN + tb) * 64 + lane, acc[ta][tb]);
+        return;
+    }
     // epilogue: C/D map (cdna_hip_programming.md section 3): col = lane % MF,
     // row = 8*(reg>>2) + 4*(lane / MF) + (reg & 3)
 #pragma unroll

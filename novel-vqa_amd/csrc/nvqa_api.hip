@@ -20,6 +20,7 @@
 #include "lstm_persist.h"
 #include "lstm_persist_bwd.h"
 #include "wgrad_bf16.h"
+#include "lstm_bwd_level.h"
 #include "nvqa_ctx.h"
 
 using namespace nvqa;
@@ -323,7 +324,14 @@ static int create_impl(nvqa_ctx *c)
     NVQA_TRY(dalloc(&c->colpart, 64 * widest));
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
-    NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * B * R));
+    // (rows and units padded to whole 64 x 64 tiles: the fused level kernel stores tile-native slabs)
+    NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * ((B + 63) / 64 * 64) * ((R + 63) / 64 * 64)));
+    { // arrival counters of the fused BPTT levels (lstm_bwd_level.h): [diagonal][layer][output tile]
+        const char *e = getenv("NVQA_BWD_FUSE");
+        c->bwd_fuse = e && e[0] == '1'; // opt-in: measured slower than the two-launch form (lstm_bwd_level.h)
+        c->bwd_cnt_words = (size_t)(TS + L) * NVQA_MAX_LAYERS * ((R + 63) / 64) * ((B + 63) / 64);
+        NVQA_TRY(dalloc(&c->bwd_cnt, c->bwd_cnt_words));
+    }
     {   // LDS-DMA ring level kernels (gemm_ring.h): opt-in with NVQA_RING=1.  Measured equal to the
         // register-staged kernels within +-4 % (tools/kbench6, kbench9), so they are not the default.
         const char *ef = getenv("NVQA_FOLD_I2H");
@@ -373,7 +381,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
                     c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT, c->mc,
-                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
+                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->bwd_cnt, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int l = 0; l < NVQA_MAX_LAYERS; ++l) {
@@ -918,6 +926,11 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         }
         NVQA_HIP(hipGetLastError());
     }
+    // NVQA_BWD_FUSE=1: slab sums + cell backward inside the level kernel (lstm_bwd_level.h) instead of a second launch per
+    // level (k_lstm_bwd_finish); parity-green, slower, off by default
+    const int fuse_tiles = ((R + CfgBwdLevel::BN - 1) / CfgBwdLevel::BN) * ((B + CfgBwdLevel::BM - 1) / CfgBwdLevel::BM);
+    const bool fuse = c->bwd_fuse && !ring && c->bwd_cnt && (size_t)(TS + L) * NVQA_MAX_LAYERS * fuse_tiles <= c->bwd_cnt_words;
+    if (fuse) NVQA_HIP(hipMemsetAsync(c->bwd_cnt, 0, (size_t)(TS + L) * NVQA_MAX_LAYERS * fuse_tiles * 4, c->s));
     for (int dg = 0; dg < TS + L - 1; ++dg) {
         // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j).
         // Products of the level: dG_{s+1} W_h2h (none at the last step) and, below the top layer,
@@ -926,8 +939,11 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         BwdFinish fin;
         fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R;
         int np = 0, nf = 0;
+        int fin_of[NVQA_MULTI_MAX] = {}, nprod[NVQA_MAX_LAYERS] = {};
         double flops = 0, bytes = 0;
         const size_t slab = (size_t)B * R;
+        // stride between the K slices' slabs: [B][R] row-major, or (fused) whole tiles in the products' register order
+        const size_t slab_st = fuse ? (size_t)fuse_tiles * CfgBwdLevel::BM * CfgBwdLevel::BN : slab;
         for (int l = L - 1; l >= 0; --l) {
             const int s = TS - 1 - (dg - (L - 1 - l));
             if (s < 0 || s >= TS) continue;
@@ -945,22 +961,24 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
             e.R = R;
             e.sort_idx = c->sort_idx; e.B = B; e.T = TS; e.s = s; e.lm1 = l; e.dr = dr;
             e.has_upper = top ? 0 : 1;
-            float *srec = c->chain_slabs + ((size_t)l * 2 + 0) * NVQA_BWD_Z * slab;
-            float *sup = c->chain_slabs + ((size_t)l * 2 + 1) * NVQA_BWD_Z * slab;
+            float *srec = c->chain_slabs + ((size_t)l * 2 + 0) * NVQA_BWD_Z * slab_st;
+            float *sup = c->chain_slabs + ((size_t)l * 2 + 1) * NVQA_BWD_Z * slab_st;
             fin.srec[nf] = last ? nullptr : srec;
             fin.sup[nf] = top ? nullptr : sup;
             if (!last) {
                 ma.g[np] = mkargs(c->Gt[l] + (size_t)(s + 1) * B * 4 * R, 4 * R, c->P + c->lo.w_h2h[l], R, B, R, 4 * R,
                                   4 * R / NVQA_BWD_Z, 0, c->nrows + s);
                 if (ring) { ma.g[np].B = c->WT + ((size_t)l * 2 + 0) * wt; ma.g[np].ldb = 4 * R; }
-                ma.e[np] = EpiStore{srec, R, slab};
+                ma.e[np] = EpiStore{srec, R, slab_st};
+                fin_of[np] = nf; ++nprod[nf];
                 ++np;
             }
             if (!top) {
                 ma.g[np] = mkargs(c->Gt[l + 1] + (size_t)s * B * 4 * R, 4 * R, c->P + c->lo.w_i2h[l + 1], R, B, R, 4 * R,
                                   4 * R / NVQA_BWD_Z, 0, c->nrows + s);
                 if (ring) { ma.g[np].B = c->WT + ((size_t)(l + 1) * 2 + 1) * wt; ma.g[np].ldb = 4 * R; }
-                ma.e[np] = EpiStore{sup, R, slab};
+                ma.e[np] = EpiStore{sup, R, slab_st};
+                fin_of[np] = nf; ++nprod[nf];
                 ++np;
             }
             const double nseg = (last ? 0 : 1) + (top ? 0 : 1);
@@ -972,13 +990,38 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z;
             ma.xcd = xcd_order(); // natural order: every XCD reads all of dG (105 MB of fabric traffic per level, PMC)
-            if (ring) NVQA_HIP((launch_gemm_ring_multi<false, EpiStore, 0>(c->s, ma, np)));
+            if (fuse) { // products + slab sums + cell backward in one launch (lstm_bwd_level.h)
+                MultiArgs<EpiSlabTile> ms;
+                BwdFuse f;
+                f.fin = fin;
+                for (int p = 0; p < np; ++p) {
+                    ms.g[p] = ma.g[p];
+                    ms.e[p] = EpiSlabTile{ma.e[p].C, ma.e[p].slab, (unsigned)(CfgBwdLevel::BM * CfgBwdLevel::BN), (unsigned)(NVQA_BWD_Z * slab_st * 4)};
+                    f.fin_of[p] = fin_of[p];
+                }
+                for (int i = 0; i < nf; ++i) f.target[i] = (unsigned)(NVQA_BWD_Z * nprod[i]);
+                f.cnt = c->bwd_cnt + (size_t)dg * NVQA_MAX_LAYERS * fuse_tiles;
+                ms.zsplit = ma.zsplit; ms.xcd = ma.xcd;
+                if (c->bf16) NVQA_HIP((launch_gemm_bwd_level<WithBF<CfgBwdLevel>::type, A_KC, B_NC>(c->s, ms, np, f)));
+                else NVQA_HIP((launch_gemm_bwd_level<CfgBwdLevel, A_KC, B_NC>(c->s, ms, np, f)));
+            } else if (ring) NVQA_HIP((launch_gemm_ring_multi<false, EpiStore, 0>(c->s, ma, np)));
             else if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgBwdLevel>::type, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
             else NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
         {
-            ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nf * slab * (2.0 * NVQA_BWD_Z + 14) * 4);
-            hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nf), dim3(256), 0, c->s, fin);
+            // the separate finisher: every cell problem of the level, or (fused levels) only those without a product --
+            // the top layer at the last step
+            BwdFinish rest = fin;
+            int nr = nf;
+            if (fuse) {
+                nr = 0;
+                for (int i = 0; i < nf; ++i)
+                    if (nprod[i] == 0) { rest.e[nr] = fin.e[i]; rest.srec[nr] = nullptr; rest.sup[nr] = nullptr; ++nr; }
+            }
+            if (nr > 0) {
+                ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nr * slab * (2.0 * NVQA_BWD_Z + 14) * 4);
+                hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nr), dim3(256), 0, c->s, rest);
+            }
         }
         NVQA_HIP(hipGetLastError());
     }

@@ -112,6 +112,9 @@ struct nvqa_ctx {
     float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
     float *dqc = nullptr, *dic = nullptr;
     float *colpart = nullptr, *slabs = nullptr;
+    unsigned *bwd_cnt = nullptr;  // arrival counters of the fused BPTT levels (lstm_bwd_level.h)
+    size_t bwd_cnt_words = 0;
+    bool bwd_fuse = false;        // NVQA_BWD_FUSE=1: slab sums + cell backward inside the level kernel (slower: off)
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
     float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
     bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate

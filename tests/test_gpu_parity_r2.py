@@ -285,3 +285,28 @@ def test_persistent_bptt_opt_in(pkg, orc, name):
             b[0][:, 11:] = 0
         _check_step(pkg, orc, d, ctx, params, b, orc.Dropout(1, 0.5, 123, 20 + it), TOL_GRAD, f"persist_bwd_{name}_{it}")
     ctx.close()
+
+
+@pytest.mark.parametrize("kw", [dict(arch=1, B=200, T=9, V=300, E=40, R=96, L=3, I=64, C=32, A=24),
+                                dict(arch=2, B=128, T=7, V=300, E=64, R=64, L=2, I=48, C=4, A=24)])
+def test_fused_bptt_level_opt_in(pkg, orc, kw):
+    """NVQA_BWD_FUSE=1 (csrc/lstm_bwd_level.h): slab sums + cell backward inside the level kernel, the last workgroup of a
+    tile to arrive finishing it.  Not the default (measured slower); kept bit-identical to the two-launch form: same z
+    order of the partial sums.  B = 200 / R = 96: partial row and unit tiles; L = 3: three cell problems on a diagonal."""
+    d = orc.make_dims(**kw)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d, seed=3, full_length=False, min_len=2)
+    lens = lens if d.arch == 1 else None
+    dr = gdrop(pkg, orc.Dropout(1, 0.5, 123, 5))
+    out = []
+    for env in ({"NVQA_BWD_FUSE": "1"}, {"NVQA_BWD_FUSE": "0"}):
+        ctx = _ctx(pkg, d, env)
+        ctx.set_params(params)
+        loss = ctx.step(tok, lens, img, lab, dr)
+        out.append((loss, ctx.get_grads()))
+        l2 = ctx.step(tok, lens, img, lab, dr)
+        assert l2 == loss and np.array_equal(ctx.get_grads(), out[-1][1])
+        ctx.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    ref = orc.Oracle(np.float64).step(d, params, tok, lens, img, lab, orc.Dropout(1, 0.5, 123, 5))
+    assert_grads(orc, d, out[0][1], ref["grads"], TOL_GRAD, "fused_bptt_level")
