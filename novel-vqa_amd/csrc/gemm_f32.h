@@ -703,6 +703,17 @@ __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_kernel(Ge
     }
 }
 
+// K slices of a level product whose rows beyond *mlimit are inactive: the fewer row tiles have work, the deeper the
+// split, so that the level still fills the chip and each workgroup's K loop gets shorter (a BPTT level of a ragged batch:
+// B = 512: 8 row tiles -> 4 slices, the tuned full-batch form; 4 -> 8; 1 or 2 -> 16): as deep as the workgroups of the
+// launch (all row tiles x zbase slices per column tile) allow.  Producer and finisher use the same rule.
+__host__ __device__ inline int zsplit_for(int active_mtiles, int all_mtiles, int zbase, int zmax)
+{
+    int z = zbase;
+    while (z * 2 <= zmax && active_mtiles * z * 2 <= all_mtiles * zbase) z *= 2;
+    return z;
+}
+
 // Several independent problems of the same shape class in ONE launch (blockIdx.z = problem):
 // the LSTM steps of different layers on one wavefront diagonal.  More workgroups per launch
 // (two per CU overlap each other's prologue / epilogue) and one kernel boundary per diagonal.
@@ -711,6 +722,10 @@ template <class Epi> struct MultiArgs {
     GemmArgs g[NVQA_MULTI_MAX];
     Epi e[NVQA_MULTI_MAX];
     int zsplit = 1; // K slices per problem (cross-CU split-K: the epilogue sees z and writes a slab)
+    int zadapt = 0; // != 0 (ragged BPTT levels): the deepest split allowed; each problem then uses zsplit_for(its active row
+                    // tiles, zsplit, zadapt) slices, chosen on the device from *g.mlimit, and the launch's workgroups of
+                    // that problem (still row tiles x column tiles x zsplit of them) are re-dealt over (active row tile,
+                    // column tile, slice): inactive row tiles are not computed, idle workgroups leave at once
     int xcd = 0;    // fold the hardware workgroup id so that each XCD owns a contiguous range of the x-fastest
                     // (tile, K slice, problem) order: one K slice of one problem per XCD shares its operand slabs in L2
 };
@@ -733,6 +748,16 @@ __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_multi_ker
         bx = j % nx; by = (j / nx) % ny; bz = j / (nx * ny);
     }
     const int p = bz / a.zsplit, z = bz % a.zsplit;
+    if (a.zadapt) {
+        const int nr = min(a.g[p].M, *a.g[p].mlimit), mt = (nr + C::BM - 1) / C::BM;
+        const int ze = zsplit_for(mt, (int)gridDim.y, a.zsplit, a.zadapt); // mt * ze <= row tiles * zsplit: the problem's workgroups suffice
+        const unsigned nx = gridDim.x, slot = bx + nx * (by + gridDim.y * z);
+        if (slot >= nx * mt * ze) return; // (nobody reads the inactive rows of the slabs: the finisher writes their zeros)
+        GemmArgs g = a.g[p];
+        g.kslice = (g.K / ze + C::BK - 1) / C::BK * C::BK;
+        gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(g, a.e[p], slot % nx, (slot / nx) % mt, slot / (nx * mt));
+        return;
+    }
     gemm_f32_body<C, AMODE, BMODE, GATES, Epi, SEG>(a.g[p], a.e[p], bx, by, z);
 }
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/nvqa_layout.h"
 #include "epilogues.h"
+#include "gemm_f32.h"
 
 namespace nvqa {
 
@@ -760,6 +761,7 @@ struct BwdFinish {
     const float *srec[NVQA_MAX_LAYERS]; // [Z][B][R] partials of dG_{s+1} W_h2h, or NULL
     const float *sup[NVQA_MAX_LAYERS];  // [Z][B][R] partials of dG^{l+1}_s W_i2h^{l+1}, or NULL
     int Z, B, R;
+    int zadapt; // != 0: the products chose their number of K slices from nrows (gemm_f32.h zsplit_for(tiles, Z, zadapt))
 };
 __global__ void k_lstm_bwd_finish(BwdFinish a)
 {
@@ -772,10 +774,11 @@ __global__ void k_lstm_bwd_finish(BwdFinish a)
     const EpiLstmBwd::Pre q = e.preload(m, u);
     float v = 0.f, v2 = 0.f;
     if (m < q.nr) {
+        const int Z = a.zadapt ? zsplit_for((min(q.nr, a.B) + 63) / 64, (a.B + 63) / 64, a.Z, a.zadapt) : a.Z; // 64 = CfgBwdLevel::BM
         if (a.srec[p])
-            for (int z = 0; z < a.Z; ++z) v += a.srec[p][(size_t)z * n + i];
+            for (int z = 0; z < Z; ++z) v += a.srec[p][(size_t)z * n + i];
         if (a.sup[p])
-            for (int z = 0; z < a.Z; ++z) v2 += a.sup[p][(size_t)z * n + i];
+            for (int z = 0; z < Z; ++z) v2 += a.sup[p][(size_t)z * n + i];
     }
     e(0, m, u, v, v2, q);
 }

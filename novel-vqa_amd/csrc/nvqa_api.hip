@@ -104,6 +104,7 @@ typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgBig16;
 typedef Cfg<16, 64, 32, 32, 4, 2, 1, 1> CfgNarrow; // 64 x 32 tiles, 8 waves of 16 x 16: products whose 64 x 64 tiling leaves half the
                                                    // CUs idle (W_o, dzd: 128 tiles; 20 vs 27 us) or whose N wastes wide tiles (d(input), N = 200: 122 vs 140 us)
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
+#define NVQA_BWD_ZMAX 16 // ... of a ragged batch's levels with few active row tiles (gemm_f32.h zsplit_for)
 typedef Cfg<16, 64, 64, 64, 4, 1, 2, 1> CfgLstmFwd; // 8 waves: 2 K-groups x 4 row tiles of 16 rows x 16 units x 4 gates (tools/kbench4: 37.5 vs 44.3 us per level)
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgBwdLevel; // 8 waves of 16x32 (tools/kbench2: 34.2 vs 38.9 us per level for the 32x32x2 form)
 
@@ -325,7 +326,7 @@ static int create_impl(nvqa_ctx *c)
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
     // (rows and units padded to whole 64 x 64 tiles: the fused level kernel stores tile-native slabs)
-    NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_Z * ((B + 63) / 64 * 64) * ((R + 63) / 64 * 64)));
+    NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_ZMAX * ((B + 63) / 64 * 64) * ((R + 63) / 64 * 64)));
     { // arrival counters of the fused BPTT levels (lstm_bwd_level.h): [diagonal][layer][output tile]
         const char *e = getenv("NVQA_BWD_FUSE");
         c->bwd_fuse = e && e[0] == '1'; // opt-in: measured slower than the two-launch form (lstm_bwd_level.h)
@@ -931,13 +932,19 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
     const int fuse_tiles = ((R + CfgBwdLevel::BN - 1) / CfgBwdLevel::BN) * ((B + CfgBwdLevel::BM - 1) / CfgBwdLevel::BM);
     const bool fuse = c->bwd_fuse && !ring && c->bwd_cnt && (size_t)(TS + L) * NVQA_MAX_LAYERS * fuse_tiles <= c->bwd_cnt_words;
     if (fuse) NVQA_HIP(hipMemsetAsync(c->bwd_cnt, 0, (size_t)(TS + L) * NVQA_MAX_LAYERS * fuse_tiles * 4, c->s));
+    // ragged arch1 batches (or lengths known only on the device): the products pick their split-K depth from nrows[s] on
+    // the device -- a level with 2 of 8 row tiles active runs 16 short K slices instead of 4 long ones; the launch's workgroups are
+    // re-dealt over (active row tile, column tile, slice).  NVQA_BWD_ZADAPT=0 switches it off.
+    static const bool zad_on = [] { const char *e = getenv("NVQA_BWD_ZADAPT"); return !(e && e[0] == '0'); }();
+    const bool zad = zad_on && d.arch == NVQA_ARCH1 && !c->batch_uniform && !ring && !fuse && (4 * R) % (NVQA_BWD_ZMAX * 32) == 0;
+    const int Zl = zad ? NVQA_BWD_ZMAX : NVQA_BWD_Z;
     for (int dg = 0; dg < TS + L - 1; ++dg) {
         // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j).
         // Products of the level: dG_{s+1} W_h2h (none at the last step) and, below the top layer,
         // dG^{l+1}_s W_i2h^{l+1}; all are [B x 4R] x [4R x R] -> split-K GEMMs into slabs in ONE launch.
         MultiArgs<EpiStore> ma;
         BwdFinish fin;
-        fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R;
+        fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R; fin.zadapt = zad ? NVQA_BWD_ZMAX : 0;
         int np = 0, nf = 0;
         int fin_of[NVQA_MULTI_MAX] = {}, nprod[NVQA_MAX_LAYERS] = {};
         double flops = 0, bytes = 0;
@@ -961,8 +968,8 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
             e.R = R;
             e.sort_idx = c->sort_idx; e.B = B; e.T = TS; e.s = s; e.lm1 = l; e.dr = dr;
             e.has_upper = top ? 0 : 1;
-            float *srec = c->chain_slabs + ((size_t)l * 2 + 0) * NVQA_BWD_Z * slab_st;
-            float *sup = c->chain_slabs + ((size_t)l * 2 + 1) * NVQA_BWD_Z * slab_st;
+            float *srec = c->chain_slabs + ((size_t)l * 2 + 0) * Zl * slab_st;
+            float *sup = c->chain_slabs + ((size_t)l * 2 + 1) * Zl * slab_st;
             fin.srec[nf] = last ? nullptr : srec;
             fin.sup[nf] = top ? nullptr : sup;
             if (!last) {
@@ -988,7 +995,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         }
         if (np > 0) {
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
-            ma.zsplit = NVQA_BWD_Z;
+            ma.zsplit = NVQA_BWD_Z; ma.zadapt = zad ? NVQA_BWD_ZMAX : 0;
             ma.xcd = xcd_order(); // natural order: every XCD reads all of dG (105 MB of fabric traffic per level, PMC)
             if (fuse) { // products + slab sums + cell backward in one launch (lstm_bwd_level.h)
                 MultiArgs<EpiSlabTile> ms;
