@@ -16,9 +16,9 @@ import sys
 
 GROUPS = [
     ("lstm_step_fwd", lambda n: "k_lstm_fwd_persist" in n or ("gemm_f32_multi_kernel" in n and "EpiLstmFwd" in n)),
-    ("lstm_step_bwd", lambda n: "gemm_f32_multi_kernel" in n and "EpiStore" in n),
+    ("lstm_step_bwd", lambda n: "k_lstm_bwd_persist" in n or "gemm_bwd_level_kernel" in n or ("gemm_f32_multi_kernel" in n and "EpiStore" in n)),
     ("lstm_bwd_finish", lambda n: "k_lstm_bwd_finish" in n),
-    ("gemm_wgrad", lambda n: "gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n),
+    ("gemm_wgrad", lambda n: "k_wgrad_bf16" in n or ("gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n)),
     # i2h forward and the classifier's W_o product share a kernel (EpiBias2, K-contiguous x K-contiguous): the
     # time-batched one is the launch with more than a million threads
     ("gemm_i2h_fwd", lambda n, grid=0: "gemm_f32_kernel" in n and "EpiBias2" in n and grid > (1 << 20)),
