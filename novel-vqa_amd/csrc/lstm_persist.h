@@ -238,6 +238,12 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     const int jmaxb = (int)growb < B ? (B - (int)growb + 32 * RBn - 1) / (32 * RBn) : 0;
 
     int mt_cur = MT, mt_nxt = MT; // RAG: row tiles with active rows at this step / at the next one
+    // The layer-0 instance of a model whose layers differ (arch1: G0 != G1) does not multiply the recurrent chunks of its
+    // FIRST active step (h_{-1} = 0, and before a late row block starts its h slices are written as zeros: their loads, LDS traffic and barriers stay -- the chunk pipeline is untouched -- only the
+    // MFMAs go, behind a wave-uniform branch per pair).  Layer 0 is not the critical path (K = 712 against 1024), so the
+    // branches cost nothing there, and every layer above starts 8 chunks x 1.7 us earlier: the launch is that much shorter.
+    constexpr bool SKIP0 = !BF && G0 != G1; // (bf16: the step is issue-bound, not MFMA-bound: the branches cost more than the MFMAs)
+    bool skip_rec = false;
     pf_u32x4 stg[D][MT];
     unsigned pend = 0; // value of the counter the next flagged chunk depends on, requested a chunk ahead of its use
     // ask for the counter that chunk q of step t waits for (always a load -- of counter 0 when nothing is awaited --
@@ -361,7 +367,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
             };
             auto pair = [&](auto mp_tag) {
                 constexpr int mp = decltype(mp_tag)::value;
-                if (!RAG || mp < mt_cur) {
+                if ((!RAG || mp < mt_cur) && !(SKIP0 && s1 && skip_rec)) {
                     if constexpr (!BF) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w)
@@ -511,6 +517,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
         // limit this kernel runs at, hipcc 7.2 lost the high half in one build and the add went astray.)
         int pub = -1;
         for (int t = t_lo; t < t_hi; ++t) {
+            if constexpr (SKIP0) skip_rec = __builtin_amdgcn_readfirstlane((t == t_lo && !(a.h0_top && l == a.L - 1)) ? 1 : 0) != 0;
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             const bool more = t + 1 < t_hi;
