@@ -65,6 +65,9 @@ FULL_BF16 = {
     "arch1_all26": dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000),
     # question lengths 3 .. 26: the RAG + bf16 instances of both persistent kernels (row tiles without active rows skipped)
     "arch1_ragged": dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000),
+    # one layer: the MT = 4 instances of the forward kernel and the 32-unit (NTN = 2) bf16 instance of the BPTT kernel
+    "arch2_L1": dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000),
+    "arch1_L1_ragged": dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=1, I=4096, C=1024, A=1000),
 }
 
 

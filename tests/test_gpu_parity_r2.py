@@ -231,6 +231,7 @@ PERSIST_CASES = {   # (dims, batch A full-length?, batch B: uniform length or No
     "arch2_L2": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=2, I=2048, C=4, A=1000), False, None),
     "arch2_L1": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000), False, None),
     "arch1_B200": (dict(FULL1, B=200), True, 5),    # 13 row tiles: partial row block, fewer workgroups than CUs
+    "arch1_L1_ragged": (dict(FULL1, L=1), False, None),  # one layer: 4 row tiles per workgroup (MT = 4), ragged instance
 }
 
 
@@ -268,7 +269,7 @@ def test_persistent_forward_lstm(pkg, orc, name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["arch1_all26", "arch2_L2", "arch2_L1", "arch1_ragged"])
+@pytest.mark.parametrize("name", ["arch1_all26", "arch2_L2", "arch2_L1", "arch1_ragged", "arch1_L1_ragged"])
 def test_persistent_bptt_opt_in(pkg, orc, name):
     """NVQA_PERSIST_BWD=1: BPTT as one persistent launch with three workgroup roles (csrc/lstm_persist_bwd.h) -- not the
     default (it only ties the per-level kernels), kept parity-green against the f64 oracle."""
