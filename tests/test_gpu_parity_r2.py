@@ -232,6 +232,7 @@ PERSIST_CASES = {   # (dims, batch A full-length?, batch B: uniform length or No
     "arch2_L1": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000), False, None),
     "arch1_B200": (dict(FULL1, B=200), True, 5),    # 13 row tiles: partial row block, fewer workgroups than CUs
     "arch1_L1_ragged": (dict(FULL1, L=1), False, None),  # one layer: 4 row tiles per workgroup (MT = 4), ragged instance
+    "arch1_E512_ragged": (dict(FULL1, E=512), False, None),  # an arch1 model as wide as arch2: the E = 512 instances with RAG
 }
 
 
