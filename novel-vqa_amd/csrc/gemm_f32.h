@@ -742,6 +742,14 @@ __global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_multi_ker
         bz = k / 4;
         bx = (k % 4) * qx + local % qx;
         by = local / qx;
+    } else if (a.xcd == 3 && gridDim.x % 4 == 0 && gridDim.y % 2 == 0) {
+        // BPTT level: XCD k = id % 8 owns (row half k / 4, column quarter k % 4) of every
+        // product and K slice: its L2 sees half of each dG and a quarter of each W instead of all of dG and an eighth of W
+        const unsigned nx = gridDim.x, ny = gridDim.y, qx = nx / 4, hy = ny / 2;
+        const unsigned id = bx + nx * (by + ny * bz), k = id % 8, local = id / 8;
+        bx = (k % 4) * qx + local % qx;
+        by = (k / 4) * hy + (local / qx) % hy;
+        bz = local / (qx * hy);
     } else if (a.xcd) {
         const unsigned nx = gridDim.x, ny = gridDim.y;
         const unsigned j = xcd_fold(bx + nx * (by + ny * bz), nx * ny * gridDim.z);

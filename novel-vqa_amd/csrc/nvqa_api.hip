@@ -996,7 +996,12 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         if (np > 0) {
             ProfScope ps(c, PF_LSTM_BWD, flops, bytes);
             ma.zsplit = NVQA_BWD_Z; ma.zadapt = zad ? NVQA_BWD_ZMAX : 0;
-            ma.xcd = xcd_order(); // natural order: every XCD reads all of dG (105 MB of fabric traffic per level, PMC)
+            // tile -> XCD map: (row half, column quarter) per XCD where the tile grid allows it (each L2 then sees half of
+            // every dG and a quarter of every W: 0.3 % of the step against the natural order, in which every XCD reads all
+            // of dG -- 105 MB of fabric traffic per level, PMC); NVQA_BWD_MAP=0 restores the natural order
+            static const int bmap = [] { const char *e = getenv("NVQA_BWD_MAP"); return e ? atoi(e) : 3; }();
+            const bool grid2d = ((R + CfgBwdLevel::BN - 1) / CfgBwdLevel::BN) % 4 == 0 && ((B + CfgBwdLevel::BM - 1) / CfgBwdLevel::BM) % 2 == 0;
+            ma.xcd = bmap == 3 && grid2d && !zad ? 3 : xcd_order();
             if (fuse) { // products + slab sums + cell backward in one launch (lstm_bwd_level.h)
                 MultiArgs<EpiSlabTile> ms;
                 BwdFuse f;
