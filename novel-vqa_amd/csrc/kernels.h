@@ -761,13 +761,22 @@ struct BwdFinish {
     const float *srec[NVQA_MAX_LAYERS]; // [Z][B][R] partials of dG_{s+1} W_h2h, or NULL
     const float *sup[NVQA_MAX_LAYERS];  // [Z][B][R] partials of dG^{l+1}_s W_i2h^{l+1}, or NULL
     int Z, B, R;
+    int xcd2d;  // != 0: element -> block map that follows the products' (row half, column quarter) XCD map
     int zadapt; // != 0: the products chose their number of K slices from nrows (gemm_f32.h zsplit_for(tiles, Z, zadapt))
 };
 __global__ void k_lstm_bwd_finish(BwdFinish a)
 {
     const int p = blockIdx.y;
     const size_t n = (size_t)a.B * a.R;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.xcd2d) {
+        // the level products were dealt (row half, column quarter) per XCD (gemm_f32.h, xcd == 3): block b runs on XCD
+        // b % 8 and takes its elements from that XCD's region, so the slabs come out of the L2 they were written through
+        const unsigned k = blockIdx.x % 8, local = blockIdx.x / 8, qc = a.R / 4, hr = a.B / 2; // region: hr rows x qc columns
+        const unsigned e = local * blockDim.x + threadIdx.x;                                    // element inside the region
+        if (e >= hr * qc) return;
+        i = (size_t)((k / 4) * hr + e / qc) * a.R + (k % 4) * qc + e % qc;
+    }
     if (i >= n) return;
     const int m = (int)(i / a.R), u = (int)(i % a.R);
     const EpiLstmBwd &e = a.e[p];

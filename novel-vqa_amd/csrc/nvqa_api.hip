@@ -944,7 +944,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         // dG^{l+1}_s W_i2h^{l+1}; all are [B x 4R] x [4R x R] -> split-K GEMMs into slabs in ONE launch.
         MultiArgs<EpiStore> ma;
         BwdFinish fin;
-        fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R; fin.zadapt = zad ? NVQA_BWD_ZMAX : 0;
+        fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R; fin.zadapt = zad ? NVQA_BWD_ZMAX : 0; fin.xcd2d = 0;
         int np = 0, nf = 0;
         int fin_of[NVQA_MULTI_MAX] = {}, nprod[NVQA_MAX_LAYERS] = {};
         double flops = 0, bytes = 0;
@@ -1024,6 +1024,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
             // the separate finisher: every cell problem of the level, or (fused levels) only those without a product --
             // the top layer at the last step
             BwdFinish rest = fin;
+            rest.xcd2d = (np > 0 && ma.xcd == 3 && R % 4 == 0 && B % 2 == 0 && ((size_t)B * R / 8) % 256 == 0) ? 1 : 0;
             int nr = nf;
             if (fuse) {
                 nr = 0;
