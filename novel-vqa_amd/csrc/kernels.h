@@ -780,6 +780,12 @@ __global__ void k_lstm_bwd_finish(BwdFinish a)
     if (i >= n) return;
     const int m = (int)(i / a.R), u = (int)(i % a.R);
     const EpiLstmBwd &e = a.e[p];
+    if (m >= *e.nrows) { // a question that has not started at this step: zeros, without loading its (stale) operands
+        const size_t gi = (size_t)m * 4 * e.R + u;
+        e.gates[gi] = 0.f; e.gates[gi + e.R] = 0.f; e.gates[gi + 2 * e.R] = 0.f; e.gates[gi + 3 * e.R] = 0.f;
+        e.dc[(size_t)m * e.R + u] = 0.f;
+        return;
+    }
     const EpiLstmBwd::Pre q = e.preload(m, u);
     float v = 0.f, v2 = 0.f;
     if (m < q.nr) {

@@ -1075,6 +1075,10 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
     ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
     GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
     g.mseg_limits = c->nrows; g.seg_rows = d.B;
+    // ragged arch1 batch: the XCD-contiguous tile order would give the early steps (few active rows: their row tiles
+    // leave at once) to the first XCDs and the full late steps to the last ones -- the launch then takes as long as a
+    // full-length batch (128 us either way); dealt round-robin the XCDs share the active tiles
+    if (d.arch == NVQA_ARCH1 && !c->batch_uniform) g.xcd = 0;
     // N = E: 128-wide tiles waste (256 - 200) / 256 of the MFMA work at the reference's E = 200, 32-wide ones 24 / 224
     const int w128 = (d.E + 127) / 128 * 128, w32 = (d.E + 31) / 32 * 32;
     if (w32 * 10 <= w128 * 9) {
