@@ -91,9 +91,19 @@ def cpu_baseline(w, budget_s=12.0, max_steps=24):
         steps += 1
     dt = time.perf_counter() - t0
     cores = min(int(os.environ["OMP_NUM_THREADS"]), len(os.sched_getaffinity(0)))  # threads the oracle actually used
-    return {"value": round(w["B"] * steps / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} training steps (forward + backward + clamp + RMSprop) of a B={w['B']} batch, "
-                      f"OpenMP C restatement oracle/nvqa_oracle.c, {dt:.1f} s"}
+    out = {"value": round(w["B"] * steps / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} training steps (forward + backward + clamp + RMSprop) of a B={w['B']} batch, "
+                     f"OpenMP C restatement oracle/nvqa_oracle.c, {dt:.1f} s"}
+    if w["arch"] == 1:  # BASELINE.json configs[0]: the reference's own CPU-runnable shape, batch 16 (about 2 s)
+        ts, ls, ims, las = orc.synth_batch(small)
+        xs, ms = params.copy(), np.zeros_like(params)
+        n16, t1 = 0, time.perf_counter()
+        while n16 < 64 and (n16 == 0 or time.perf_counter() - t1 < 2.0):
+            r = o.step(small, xs, ts, ls, ims, las, orc.Dropout(1, 0.5, 123, n16))
+            o.rmsprop(xs, r["grads"], ms, 3e-4)
+            n16 += 1
+        out["batch16"] = {"value": round(16 * n16 / (time.perf_counter() - t1), 2), "unit": "QA-pairs/s", "steps": n16}
+    return out
 
 
 def mean_len(w, ragged):
