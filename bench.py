@@ -265,12 +265,14 @@ def bench_end_to_end(pkg, w, local_rank, steps=2):
             "note": "on-the-fly VGG-16 fc7 (30.9 GFLOP per image) + arch1 training step; 308 MB of host images per step (PCIe inside)"}
 
 
-def bench_vgg(pkg, n=32, iters=4):
+def bench_vgg(pkg, n=32, iters=4, bf16=False):
     """VGG-16 fc7 extractor (001_prepro_img_vgg.lua), full 224x224 network, synthetic weights: images/s with host
     images in and host features out (nvqa_vgg16_fc7 as the reference script would call it)."""
     v = pkg.binding.Vgg16(0, 1, 224, max_batch=n)
     rng = np.random.default_rng(0)
     v.set_weights(vgg_synth_weights(rng))
+    if bf16:
+        v.set_precision(1)
     x = rng.uniform(-120, 130, (n, 3, 224, 224)).astype(np.float32)
     v.fc7(x)
     t0 = time.perf_counter()
@@ -280,7 +282,9 @@ def bench_vgg(pkg, n=32, iters=4):
     v.close()
     tf = 30.93 * n / dt / 1e3
     return {"value": round(n / dt, 1), "unit": "images/s", "batch": n, "ms_per_batch": round(dt * 1e3, 2),
-            "mfma_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "note": "host images in / host features out (PCIe inside the timed call)"}
+            "mfma_frac": round(tf / (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS), 4),
+            "dtype": "bf16 operands, f32 accumulate" if bf16 else "f32",
+            "note": "host images in / host features out (PCIe inside the timed call)"}
 
 
 def main():
@@ -357,6 +361,7 @@ def main():
         sec["arch1_nvqa_step_host_batches"] = {"value": hb["value"], "unit": "QA-pairs/s", "ms_per_step": hb["ms_per_step"],
                                                "note": "JdJ-shaped entry: host batch validated and copied (3 synchronous hipMemcpy) per call"}
         sec["vgg16_fc7"] = bench_vgg(pkg)
+        sec["vgg16_fc7_bf16"] = bench_vgg(pkg, bf16=True)
         sec["arch1_end_to_end_vgg16"] = bench_end_to_end(pkg, WORKLOAD, local_rank)
         out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -200,6 +200,10 @@ int nvqa_vgg16_set_weights(nvqa_vgg *vgg, const float *flat);
 /* images: n x 3 x hw x hw as loadim returns them (BGR planes, mean-subtracted, :65-70);
  * feats_out: n x F = post-ReLU fc7. */
 int nvqa_vgg16_fc7(nvqa_vgg *vgg, const float *images, int n, float *feats_out);
+/* 1: the operands of every convolution / fc product are rounded to bf16 (bf16 matrix cores, f32 accumulate; weights,
+ * activations and the features at the ABI stay f32), as nvqa_set_precision does for the training step.  The reference
+ * extracts in fp32 (001_prepro_img_vgg.lua:36,109-110): 0 is the default. */
+int nvqa_vgg16_set_precision(nvqa_vgg *vgg, int bf16);
 /* loadim's arithmetic (:50,65-69): bilinear scale of RGB [0,1] planes n x 3 x H x W to hw x hw,
  * x255, RGB->BGR, mean subtraction.  out: n x 3 x hw x hw. */
 int nvqa_vgg16_preprocess(nvqa_vgg *vgg, const float *rgb, int n, int H, int W, float *out);

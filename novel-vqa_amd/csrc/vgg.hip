@@ -127,6 +127,7 @@ struct nvqa_vgg {
     float *img = nullptr, *act[2] = {}, *slabs = nullptr, *fc6o = nullptr, *fc7o = nullptr, *nhwc_in = nullptr;
     size_t act_floats = 0;
     bool have_weights = false;
+    bool bf16 = false; // nvqa_vgg16_set_precision: operands of every convolution / fc product rounded to bf16, f32 accumulate
 };
 
 static int vgg_layout(nvqa_vgg *v)
@@ -258,7 +259,8 @@ static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, c
     GemmArgs g = {};
     g.A = x; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kslice = kslice;
     g.xcd = xcd_order();
-    NVQA_HIP((launch_gemm<CfgFc, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
+    if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgFc>::type, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
+    else NVQA_HIP((launch_gemm<CfgFc, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
     hipLaunchKernelGGL(k_fc_finish, dim3(((size_t)M * N + 255) / 256), dim3(256), 0, v->s, v->slabs, ks, M, N, b, out);
     NVQA_HIP(hipGetLastError());
     return 0;
@@ -289,9 +291,11 @@ static int vgg_forward(nvqa_vgg *v, const float *images, int n)
         const int ldc = v->coutp[i];
         if (ldc != v->cout[i]) NVQA_HIP(hipMemsetAsync(dst, 0, (size_t)g.M * ldc * 4, v->s));
         if (v->cout[i] > 64) {
-            NVQA_HIP((launch_gemm<CfgConv, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
+            if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgConv>::type, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
+            else NVQA_HIP((launch_gemm<CfgConv, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
         } else {
-            NVQA_HIP((launch_gemm<CfgConv64, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
+            if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgConv64>::type, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
+            else NVQA_HIP((launch_gemm<CfgConv64, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
         }
         cur = dst; which ^= 1;
         if (kPoolAfter[i]) {
@@ -326,6 +330,14 @@ int nvqa_vgg_forward_device(nvqa_vgg *v, const float *images, int n, const float
     *feats_dev = v->fc7o;
     *F = v->F;
     *stream = v->s;
+    return 0;
+}
+
+extern "C" int nvqa_vgg16_set_precision(nvqa_vgg *v, int bf16)
+{
+    if (!v) { set_error("vgg is NULL"); return -1; }
+    if (bf16 != 0 && bf16 != 1) { set_error("precision must be 0 (f32) or 1 (bf16 operands)"); return -1; }
+    v->bf16 = bf16 != 0;
     return 0;
 }
 

@@ -67,6 +67,7 @@ SYMBOLS = {
     "nvqa_vgg16_feature_dim": (ctypes.c_int, [_vp]),
     "nvqa_vgg16_set_weights": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_vgg16_fc7": (ctypes.c_int, [_vp, _f32p, ctypes.c_int, _f32p]),
+    "nvqa_vgg16_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_vgg16_preprocess": (ctypes.c_int, [_vp, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p]),
     "nvqa_step_images": (ctypes.c_int, [_vp, _vp, _f32p, _i32p, _i32p, _i32p, ctypes.POINTER(Dropout), _f32p]),
     "nvqa_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -317,6 +318,10 @@ class Vgg16:
         w = np.ascontiguousarray(flat, np.float32)
         assert w.size == self.weight_count
         self._check(self.lib.nvqa_vgg16_set_weights(self._h, _f32(w)))
+
+    def set_precision(self, bf16):
+        """1 = operands of the convolutions / fc products rounded to bf16 (f32 accumulate, f32 features)"""
+        self._check(self.lib.nvqa_vgg16_set_precision(self._h, int(bool(bf16))))
 
     def fc7(self, images):
         x = np.ascontiguousarray(images, np.float32)

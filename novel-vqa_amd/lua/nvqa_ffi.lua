@@ -49,6 +49,7 @@ size_t nvqa_vgg16_weight_count(const nvqa_vgg *vgg);
 int nvqa_vgg16_feature_dim(const nvqa_vgg *vgg);
 int nvqa_vgg16_set_weights(nvqa_vgg *vgg, const float *flat);
 int nvqa_vgg16_fc7(nvqa_vgg *vgg, const float *images, int n, float *feats_out);
+int nvqa_vgg16_set_precision(nvqa_vgg *vgg, int bf16);
 int nvqa_vgg16_preprocess(nvqa_vgg *vgg, const float *rgb, int n, int H, int W, float *out);
 int nvqa_step_images(nvqa_ctx *ctx, nvqa_vgg *vgg, const float *images, const int32_t *tokens,
                      const int32_t *lengths, const int32_t *labels, const nvqa_dropout *dropout, float *loss_out);

@@ -241,6 +241,10 @@ class VggOracle:
         assert w.size == self.weight_count
         return w
 
+    def set_precision(self, bf16):
+        """1 = both operands of every product rounded to bf16 first (nvqa_vgg16_set_precision); process-wide."""
+        self.lib.oracle_vgg16_set_precision(int(bool(bf16)))
+
     def fc7(self, flat, images):
         x = np.ascontiguousarray(images, np.float32)
         w = np.ascontiguousarray(flat, np.float32)

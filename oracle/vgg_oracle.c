@@ -8,6 +8,7 @@
  * NHWC formulation of the HIP path.
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -15,6 +16,20 @@ static const int kCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 51
 static const int kPool[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
 
 static int imax(int a, int b) { return a > b ? a : b; }
+
+/* bf16 operand mode (nvqa_vgg16_set_precision): both operands of every product rounded to bf16, round-to-nearest-even */
+static int g_vgg_bf16 = 0;
+void oracle_vgg16_set_precision(int bf16) { g_vgg_bf16 = bf16; }
+static float rb(float v)
+{
+    if (!g_vgg_bf16) return v;
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&v, &u, 4);
+    return v;
+}
 
 size_t oracle_vgg16_weight_count(int width_div, int hw)
 {
@@ -52,12 +67,12 @@ int oracle_vgg16_fc7(int width_div, int hw, const float *flat, const float *imag
                     const float *src = cur + ((size_t)im * cin + c) * H * W;
                     for (int ky = 0; ky < 3; ++ky)
                         for (int kx = 0; kx < 3; ++kx) {
-                            const float w = Wt[(((size_t)o * cin + c) * 3 + ky) * 3 + kx];
+                            const float w = rb(Wt[(((size_t)o * cin + c) * 3 + ky) * 3 + kx]);
                             for (int y = 0; y < H; ++y) {
                                 const int iy = y + ky - 1;
                                 if (iy < 0 || iy >= H) continue;
                                 const int x0 = kx == 0 ? 1 : 0, x1 = kx == 2 ? W - 1 : W;
-                                for (int x = x0; x < x1; ++x) dst[y * W + x] += w * src[iy * W + x + kx - 1];
+                                for (int x = x0; x < x1; ++x) dst[y * W + x] += w * rb(src[iy * W + x + kx - 1]);
                             }
                         }
                 }
@@ -94,7 +109,7 @@ int oracle_vgg16_fc7(int width_div, int hw, const float *flat, const float *imag
         for (int f = 0; f < F; ++f) {
             double acc = b6[f];
             const float *x = cur + (size_t)im * K6, *w = W6 + (size_t)f * K6; /* CHW flatten (nn.View) */
-            for (int k = 0; k < K6; ++k) acc += (double)x[k] * w[k];
+            for (int k = 0; k < K6; ++k) acc += (double)rb(x[k]) * rb(w[k]);
             f6[(size_t)im * F + f] = acc > 0 ? (float)acc : 0.f;
         }
 #pragma omp parallel for collapse(2) schedule(static)
@@ -102,7 +117,7 @@ int oracle_vgg16_fc7(int width_div, int hw, const float *flat, const float *imag
         for (int f = 0; f < F; ++f) {
             double acc = b7[f];
             const float *x = f6 + (size_t)im * F, *w = W7 + (size_t)f * F;
-            for (int k = 0; k < F; ++k) acc += (double)x[k] * w[k];
+            for (int k = 0; k < F; ++k) acc += (double)rb(x[k]) * rb(w[k]);
             out[(size_t)im * F + f] = acc > 0 ? (float)acc : 0.f;
         }
     free(cur);

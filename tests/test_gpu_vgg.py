@@ -33,6 +33,34 @@ def test_fc7_matches_oracle(pkg, orc, div, hw, n):
     v.close()
 
 
+def test_fc7_bf16_operands(pkg, orc):
+    """nvqa_vgg16_set_precision(1): every product of the extractor with both operands rounded to bf16 (f32 accumulate)
+    against the oracle's same mode; the result sits at a bf16-sized distance from the f32 features and closer to the
+    bf16 oracle than 0.75 x that distance; switching back restores the f32 path."""
+    div, hw, n = 8, 64, 5
+    vo = orc.VggOracle(div, hw)
+    w = vo.synth_weights()
+    x = np.random.default_rng(3).uniform(-110, 130, (n, 3, hw, hw)).astype(np.float32)
+    exact = vo.fc7(w, x)
+    vo.set_precision(1)
+    try:
+        ref = vo.fc7(w, x)
+    finally:
+        vo.set_precision(0)
+    v = pkg.binding.Vgg16(0, div, hw, max_batch=n)
+    v.set_weights(w)
+    v.set_precision(1)
+    got = v.fc7(x)
+    scale = np.abs(ref).max()
+    err, dist = np.abs(got - ref).max() / scale, np.abs(got - exact).max() / scale
+    # 15 layers of roundings: a flipped rounding upstream moves everything downstream (tests/test_oracle_bf16_cascade.py),
+    # so two correct bf16 implementations sit a fixed fraction of the rounding error apart -- measured 0.56 in max norm
+    assert err < 1e-2 and dist > 1e-3 and err < 0.75 * dist, (err, dist)
+    v.set_precision(0)
+    assert np.abs(v.fc7(x) - exact).max() / scale < 1e-4
+    v.close()
+
+
 def test_preprocess_matches_loadim(pkg, orc):
     rng = np.random.default_rng(1)
     rgb = rng.uniform(0, 1, (2, 3, 50, 70)).astype(np.float32)
