@@ -234,13 +234,15 @@ def vgg_synth_weights(rng):
     return np.concatenate(parts)
 
 
-def bench_end_to_end(pkg, w, local_rank, steps=2):
+def bench_end_to_end(pkg, w, local_rank, steps=2, bf16_vgg=False):
     """BASELINE.json configs[4]: the VGG-16 fc7 extractor in front of the arch1 step (nvqa_step_images: B = 512 host
     images of 3 x 224 x 224 in, features stay on the device, then the usual forward / backward; + RMSprop)."""
     dims = pkg.binding.Dims(*[w[k] for k in ("arch", "B", "T", "V", "E", "R", "L", "I", "C", "A")])
     rng = np.random.default_rng(0)
     v = pkg.binding.Vgg16(local_rank, 1, 224, max_batch=w["B"])
     v.set_weights(vgg_synth_weights(rng))
+    if bf16_vgg:
+        v.set_precision(1)
     ctx = pkg.binding.Context(dims, local_rank)
     ctx.init_params(123, -0.08, 0.08)
     x = rng.uniform(-120, 130, (w["B"], 3, 224, 224)).astype(np.float32)
@@ -262,6 +264,7 @@ def bench_end_to_end(pkg, w, local_rank, steps=2):
     ctx.close()
     v.close()
     return {"value": round(w["B"] / dt, 1), "unit": "QA-pairs/s", "ms_per_step": round(dt * 1e3, 2),
+            "extractor": "bf16 operands, f32 accumulate" if bf16_vgg else "f32",
             "note": "on-the-fly VGG-16 fc7 (30.9 GFLOP per image) + arch1 training step; 308 MB of host images per step (PCIe inside)"}
 
 
@@ -363,6 +366,7 @@ def main():
         sec["vgg16_fc7"] = bench_vgg(pkg)
         sec["vgg16_fc7_bf16"] = bench_vgg(pkg, bf16=True)
         sec["arch1_end_to_end_vgg16"] = bench_end_to_end(pkg, WORKLOAD, local_rank)
+        sec["arch1_end_to_end_vgg16_bf16_extractor"] = bench_end_to_end(pkg, WORKLOAD, local_rank, bf16_vgg=True)
         out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
