@@ -40,6 +40,8 @@ struct PersistBwdArgs {
     const float *dCT, *dHT;                           // [L][B][R] head -> final cell / hidden state gradients
     float *Pup[NVQA_PF_MAXL];                         // Pup[l], l < L-1: [TS*B][R] products of the UP(l) role
     unsigned short *Gb[NVQA_PF_MAXL];                 // bf16 instance: [TS*B][4R] bf16 image of dG (written by REC, read as A)
+    float *bias_part;                                 // [L][RB][4R]: column sums of dG over the steps and the rows of a row
+                                                      // block (the LSTM bias gradients, summed over rb by k_bias_sum)
     const int *nrows, *sort_idx, *tlast;              // tlast (arch2): dHT enters at step *tlast; NULL (arch1): at TS-1
     unsigned *cnt_rec;                                // [L][RB][TS] arrivals of the REC(l) unit tiles
     unsigned *cnt_up;                                 // [L][RB][NU][TS] flag of the UP(l) tile
@@ -53,11 +55,8 @@ struct PersistBwdArgs {
 
 template <int MT, int NTN> struct PersistBwdGeom {
     static constexpr int ROWS = 16 * MT, NST = 3, STAGE = ROWS * 64, UNITS = 16 * NTN;
-    // 64 x 64 tiles (the bf16 instance): the 48 KB that are left hold the cell-backward operands of a thread's items 2 and 3
-    // (6 arrays x 16 B x 256 threads each), brought in by LDS-DMA at the top of the step: no registers, no exposed latency
-    static constexpr bool STASH = MT == 4 && NTN == 4;
-    static constexpr int STASH_FLOATS = STASH ? 2 * 6 * NVQA_PF_THREADS * 4 : 0;
-    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWS * UNITS + STASH_FLOATS) * 4; // ring + the four waves' partial tiles (+ stash)
+    static constexpr int BSUM_FLOATS = NVQA_PF_THREADS * 16; // per thread: 4 gates x 4 units of bias-gradient partial sums
+    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWS * UNITS + BSUM_FLOATS) * 4; // ring + the four waves' partial tiles + bias sums
 };
 
 // GK: K groups (= chunks) per gate: R / 16 (f32), R / 32 (bf16); MT row tiles of 16 rows and NTN column tiles of 16 units
@@ -76,8 +75,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
     extern __shared__ __attribute__((aligned(16))) float pb_smem[];
     float *const ring = pb_smem;               // [NST][ROWS][64 words]: per row 4 gates x 16 B x 4, 16-byte pieces XOR-swizzled
     float *const Sred = pb_smem + NST * STAGE; // [4 waves][ROWS][UNITS] partial tiles
-    float *const stash = Sred + 4 * ROWS * UNITS; // (STASH) [item 2, 3][6 arrays][thread][4]
-    constexpr bool STASH = GE::STASH;
+    float *const bsum = Sred + 4 * ROWS * UNITS;   // [thread][4 gates][4 units]: sum of the thread's dG over its rows and all steps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS, L = a.L, RBn = a.RB;
 
@@ -202,6 +200,8 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
 #pragma unroll
         for (int j = 0; j < 4; ++j) dcst[e][j] = v[j];
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(bsum + (tid * 4 + g) * 4) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
     int esi[NE]; // original batch row of the owned rows (indexes the dropout stream): the same at every step
 #pragma unroll
     for (int e = 0; e < NE; ++e) esi[e] = a.sort_idx[min(rb + RBn * (erow + RPP * e), B - 1)];
@@ -234,23 +234,6 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
         if (!is_up) {
             fetch(0, 0);
             if constexpr (NE > 1) fetch(1, 1);
-            if constexpr (STASH) { // items 2 and 3: global -> LDS directly, lane l of a wave-instruction lands at base + 16 l
-                typedef __attribute__((address_space(3))) void *lds_t;
-                typedef const __attribute__((address_space(1))) void *glb_t;
-                if (!(a.dbg & 4)) {
-#pragma unroll
-                    for (int e = 2; e < NE && e < 4; ++e) {
-                        const int row = erow + RPP * e, grow = min(rb + RBn * row, B - 1);
-                        const size_t srow_g = (size_t)s * B + grow;
-                        const float *gt = a.Gt[l] + srow_g * 4 * R + u0 + 4 * eq;
-                        const float *src[6] = {gt, gt + R, gt + 2 * R, gt + 3 * R, a.Cs[l] + ((size_t)(s + 1) * B + grow) * R + u0 + 4 * eq,
-                                               a.Cs[l] + srow_g * R + u0 + 4 * eq};
-#pragma unroll
-                        for (int k = 0; k < 6; ++k)
-                            __builtin_amdgcn_global_load_lds((glb_t)src[k], (lds_t)(stash + (((e - 2) * 6 + k) * NVQA_PF_THREADS + 64 * wave) * 4), 16, 0, 0);
-                    }
-                }
-            }
         }
         // A operand: REC(l, s): dG^l_{s+1} (absent at the last step); UP(l, s): dG^{l+1}_s
         const int sa = is_up ? s : s + 1;
@@ -326,12 +309,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             const unsigned go = (unsigned)((srow_g * 4 * R + u0 + 4 * eq) * 4);
             pf_f32x4 dgi = {0.f, 0.f, 0.f, 0.f}, dgf = dgi, dgo = dgi, dgg = dgi, dcn = dgi;
             if (grow < nr) {
-                pf_f32x4 ig = e_ig[k], fg = e_fg[k], og = e_og[k], gg = e_gg[k], cc = e_cc[k], cp = e_cp[k];
-                const pf_f32x4 v2 = e_v2[e];
-                if (STASH && e >= 2) { // own slot of the stash (written by this lane's LDS-DMA loads, drained below)
-                    auto slot = [&](int k2) { return *reinterpret_cast<const pf_f32x4 *>(stash + (((e - 2) * 6 + k2) * NVQA_PF_THREADS + tid) * 4); };
-                    ig = slot(0); fg = slot(1); og = slot(2); gg = slot(3); cc = slot(4); cp = slot(5);
-                }
+                const pf_f32x4 ig = e_ig[k], fg = e_fg[k], og = e_og[k], gg = e_gg[k], cc = e_cc[k], cp = e_cp[k], v2 = e_v2[e];
                 pf_f32x4 hx = {0.f, 0.f, 0.f, 0.f};
                 if (head_now) hx = *reinterpret_cast<const pf_f32x4 *>(a.dHT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
                 const uint64_t didx = ((((uint64_t)l) * B + esi[e]) * TS + s) * R + u0 + 4 * eq;
@@ -354,6 +332,10 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgf), r_g, go + (unsigned)R * 4, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgo), r_g, go + 2u * R * 4, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgg), r_g, go + 3u * R * 4, 0, 16);
+            if (grow < nr) { // bias gradient: column sums of dG (own LDS slot: no other thread touches it)
+                pf_f32x4 *bs = reinterpret_cast<pf_f32x4 *>(bsum + tid * 16);
+                bs[0] += dgi; bs[1] += dgf; bs[2] += dgo; bs[3] += dgg;
+            }
             if constexpr (BF) { // the image the REC / UP products read (the f32 one stays what the weight gradients read)
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                 auto img = [&](const pf_f32x4 &x, unsigned gate) {
@@ -373,12 +355,11 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
                                                            r_p, has_up ? (unsigned)((((size_t)s * B + grow) * R + u0 + 4 * eq) * 4) : PF_OOB, 0, 16));
             }
         }
-        if constexpr (STASH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the LDS-DMA loads of the stash have landed (hipcc does not track them)
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             finish(e, e & 1); // dcst is indexed by the compile-time e after unrolling
-            if (!STASH && !is_up && e + 2 < NE) fetch(e + 2, e & 1); // the slot just consumed takes the item after next
+            if (!is_up && e + 2 < NE) fetch(e + 2, e & 1); // the slot just consumed takes the item after next
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
         __syncthreads();                                 // (also: Sred and the ring are free for the next step)
@@ -388,7 +369,31 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
             __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // bias gradients of this (layer, row block, unit tile): the row groups' partial sums added in a fixed order
+    if (!is_up && a.bias_part) {
+        __syncthreads();
+        if (tid < QPR) { // thread eq: the RPP threads (erow = 0 .. RPP-1) that own the same unit quad
+            pf_f32x4 s4[4] = {pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int r = 0; r < RPP; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s4[g] += *reinterpret_cast<const pf_f32x4 *>(bsum + ((r * QPR + tid) * 4 + g) * 4);
+            float *dst = a.bias_part + ((size_t)l * RBn + rb) * 4 * R + u0 + 4 * tid;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(dst + (size_t)g * R) = s4[g];
+        }
+    }
     if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
+}
+
+// LSTM bias gradients from the row blocks' partial column sums (fixed order); both bias vectors of a layer receive the sum
+__global__ void k_bias_sum(const float *part /*[RB][N]*/, int RB, int N, float *out, float *out2)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += part[(size_t)r * N + n];
+    out[n] = s;
+    out2[n] = s;
 }
 
 } // namespace nvqa

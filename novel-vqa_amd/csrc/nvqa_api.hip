@@ -363,6 +363,7 @@ static int create_impl(nvqa_ctx *c)
             const size_t rbmax = (B + 63) / 64;
             c->pb_cnt_words = (L * rbmax * TS * (1 + R / 32) + 4 + 3) / 4 * 4;
             NVQA_TRY(dalloc(&c->pb_cnt, c->pb_cnt_words));
+            NVQA_TRY(dalloc(&c->pb_bias, L * rbmax * 4 * R));
             if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
         }
     }
@@ -398,6 +399,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->act_b16) (void)hipFree(c->act_b16);
     if (c->dg_b16) (void)hipFree(c->dg_b16);
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
+    if (c->pb_bias) (void)hipFree(c->pb_bias);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
     for (hipEvent_t e : {c->evComm, c->evStart})
         if (e) (void)hipEventDestroy(e);
@@ -757,6 +759,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
     c->img_fwd_valid = c->img_bwd_valid = false;
+    c->pb_bias_rb = 0;
     if (const int MT = persist_rows(c)) { c->img_fwd_valid = c->bf16; return lstm_forward_persist(c, dr, MT); }
     // Layer 0 takes W_i2h x_t as a first K segment inside the level kernel, like the layers above it: the
     // time-batched projection (0.128 ms, a 109 MB write and its re-read by the level epilogues) costs more than
@@ -888,6 +891,8 @@ static int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     const size_t n_rec = (size_t)L * RB * TS, n_up = (size_t)L * RB * a.NU * TS;
     if (n_rec + n_up + 4 > c->pb_cnt_words) { set_error("persistent BPTT: counter block too small"); return -1; }
     a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = c->pb_cnt + c->pb_cnt_words - 4;
+    a.bias_part = c->pb_bias; // [L][RB][4R]: the kernel also leaves the LSTM bias gradients (column sums of dG) per row block
+    c->pb_bias_rb = c->pb_bias ? RB : 0;
     a.ts = c->pf_ts + 1024;
     const int grid = 256; // 8 XCDs x 32 slots (lstm_persist_bwd.h maps groups to XCDs); (2L-1) * RB * NU of them have work
     double flops = 0;
@@ -1061,7 +1066,14 @@ static int lstm_wgrads(nvqa_ctx *c, int l)
     const unsigned short *X16 = c->img_fwd_valid && l > 0 ? c->act_b16 + d.L * hs + l * us : nullptr;
     NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s, G16, H16));
     NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s, G16, X16));
-    NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
+    if (c->pb_bias_rb > 0) { // the persistent BPTT kernel of this step left the column sums per row block (lstm_persist_bwd.h)
+        ProfScope ps(c, PF_COLSUM, 0, (double)c->pb_bias_rb * 4 * R * 4);
+        hipLaunchKernelGGL(k_bias_sum, dim3((4 * R + 255) / 256), dim3(256), 0, c->s, c->pb_bias + (size_t)l * c->pb_bias_rb * 4 * R, c->pb_bias_rb,
+                           4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l]);
+        NVQA_HIP(hipGetLastError());
+    } else {
+        NVQA_TRY(colsum(c, c->Gt[l], TB, 4 * R, 4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l], c->s));
+    }
     NVQA_TRY(reduce_range(c, c->lo.w_i2h[l], c->lo.b_h2h[l] + 4 * (size_t)R - c->lo.w_i2h[l], 3 + l));
     return 0;
 }

@@ -127,6 +127,8 @@ struct nvqa_ctx {
     unsigned long long *pf_ts = nullptr; // debug timestamps of the persistent kernels (NVQA_PF_DBG & 32)
     bool img_fwd_valid = false, img_bwd_valid = false; // this step's persistent bf16 kernels wrote act_b16 / dg_b16
     bool wgrad_tr = true;              // bf16 weight gradients on the transposed-read kernel (wgrad_bf16.h)
+    float *pb_bias = nullptr;     // [L][RB][4R] LSTM bias-gradient partial sums left by the persistent BPTT kernel
+    int pb_bias_rb = 0;           // row blocks of this step's partial sums (0: none: lstm_wgrads runs the column-sum kernels)
     unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd.h)
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the err records (forward: words 0-3, BPTT: words 4-7)
