@@ -803,9 +803,25 @@ __global__ void k_lstm_bwd_finish(BwdFinish a)
 // misc/rmsprop_lrscale.lua:16-34).  gscale = 1/world for the data-parallel mean.
 // 20 B/parameter of HBM traffic (read g,m,x; write m,x).
 // ---------------------------------------------------------------------------------
-__global__ void k_rmsprop(float4 *x, const float4 *g, float4 *m, size_t n4, float lr, float alpha,
-                          float eps, float wd, float clamp, float gscale)
+// LSTM bias gradients from the row blocks' partial column sums (fixed order); both bias vectors of a layer receive the sum
+__global__ void k_bias_sum(const float *part /*[RB][N]*/, int RB, int N, float *out, float *out2)
 {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += part[(size_t)r * N + n];
+    out[n] = s;
+    out2[n] = s;
+}
+
+// skip: the sticky err records of the persistent LSTM kernels (8 words, persist_fwd.hip: k_err_latch); dp_skip (data
+// parallel): the number of ranks whose kernel gave up in this step.  While either is set the step's gradients are
+// invalid and nothing is applied -- the host reports the failed step at its next synchronisation point.
+__global__ void k_rmsprop(float4 *x, const float4 *g, float4 *m, size_t n4, float lr, float alpha,
+                          float eps, float wd, float clamp, float gscale, const unsigned *skip, const float *dp_skip)
+{
+    if (skip && (skip[0] | skip[4]) != 0u) return;
+    if (dp_skip && dp_skip[0] != 0.f) return;
     const float om = 1.0f - alpha;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (size_t)gridDim.x * blockDim.x) {

@@ -385,15 +385,4 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist(Persist
     if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
 }
 
-// LSTM bias gradients from the row blocks' partial column sums (fixed order); both bias vectors of a layer receive the sum
-__global__ void k_bias_sum(const float *part /*[RB][N]*/, int RB, int N, float *out, float *out2)
-{
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += part[(size_t)r * N + n];
-    out[n] = s;
-    out2[n] = s;
-}
-
 } // namespace nvqa

@@ -17,11 +17,10 @@
 #include "gemm_f32.h"
 #include "gemm_ring.h"
 #include "kernels.h"
-#include "lstm_persist.h"
-#include "lstm_persist_bwd.h"
 #include "wgrad_bf16.h"
 #include "lstm_bwd_level.h"
 #include "nvqa_ctx.h"
+#include "persist_host.h"
 
 using namespace nvqa;
 
@@ -41,7 +40,7 @@ void set_error(const char *fmt, ...)
 extern "C" const char *nvqa_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------
-// profiling scope: brackets the launches of one group with HIP events on ctx->s
+// profiling (scope: prof.h)
 // ------------------------------------------------------------------------------------
 static const char *kProfNames[PF_COUNT] = {
     "assemble",      "emb_fwd",       "gemm_i2h_fwd", "lstm_step_fwd", "head_prep", "gemm_head_fwd",
@@ -49,29 +48,6 @@ static const char *kProfNames[PF_COUNT] = {
     "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch", "lstm_bwd_finish",
     "transpose_w"};
 
-struct ProfScope {
-    nvqa_ctx *c;
-    int id;
-    hipStream_t st;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(nvqa_ctx *c_, int id_, double flops = 0, double bytes = 0, hipStream_t st_ = nullptr)
-        : c(c_), id(id_), st(st_ ? st_ : c_->s)
-    {
-        if (!c->prof_on) return;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, st);
-        c->prof[id].flops += flops;
-        c->prof[id].bytes += bytes;
-        c->prof[id].launches += 1;
-    }
-    ~ProfScope()
-    {
-        if (!c->prof_on) return;
-        (void)hipEventRecord(e1, st);
-        c->prof[id].pending.emplace_back(e0, e1);
-    }
-};
 
 static void prof_collect(nvqa_ctx *c)
 {
@@ -353,19 +329,23 @@ static int create_impl(nvqa_ctx *c)
         NVQA_HIP(hipMemsetAsync(c->pf_ts, 0, 2048 * 8, c->s));
         NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 8 * sizeof(unsigned), hipHostMallocDefault));
         memset(c->h_pf_err, 0, 32);
-        // persistent BPTT (lstm_persist_bwd.h): opt-in with NVQA_PERSIST_BWD=1 -- parity-green, but at 46 us per step it
-        // only ties the per-level kernels (33.5 + 8.2 us): its serial part per step (counter wait 4 us, pipeline prologue
-        // 2 us, K-quarter reduction + cell backward + write-through drain 9 us) cannot hide behind an independent K
-        // segment the way the forward kernel's does
+        // persistent BPTT (lstm_persist_bwd2.h / lstm_persist_bwd.h): default where the shape is eligible; NVQA_PERSIST_BWD=0: the
+        // per-level kernels
         const char *eb = getenv("NVQA_PERSIST_BWD");
-        c->persist_bwd_on = !eb ? -1 : (eb[0] == '1' ? 1 : 0); // unset: on for the bf16 instance only (persist_bwd_rows)
+        c->persist_bwd_on = !eb ? -1 : (eb[0] == '1' ? 1 : 0);
         if (d.R == 512 && L <= 2) {
             const size_t rbmax = (B + 63) / 64;
-            c->pb_cnt_words = (L * rbmax * TS * (1 + R / 32) + 4 + 3) / 4 * 4;
+            c->pb_cnt_words = persist_bwd_counter_words(d, (int)TS);
             NVQA_TRY(dalloc(&c->pb_cnt, c->pb_cnt_words));
             NVQA_TRY(dalloc(&c->pb_bias, L * rbmax * 4 * R));
             if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
         }
+        NVQA_TRY(dalloc(&c->pf_sticky, 8));
+        NVQA_HIP(hipMemsetAsync(c->pf_sticky, 0, 32, c->s));
+        NVQA_TRY(dalloc(&c->dp_status, 4));
+        NVQA_HIP(hipMemsetAsync(c->dp_status, 0, 16, c->s));
+        NVQA_HIP(hipHostMalloc((void **)&c->h_dp_status, 4 * sizeof(float), hipHostMallocDefault));
+        memset(c->h_dp_status, 0, 16);
     }
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
@@ -401,6 +381,9 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
     if (c->pb_bias) (void)hipFree(c->pb_bias);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
+    if (c->pf_sticky) (void)hipFree(c->pf_sticky);
+    if (c->dp_status) (void)hipFree(c->dp_status);
+    if (c->h_dp_status) (void)hipHostFree(c->h_dp_status);
     for (hipEvent_t e : {c->evComm, c->evStart})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evSeg)
@@ -440,6 +423,7 @@ static int check_persist(nvqa_ctx *c)
         set_error("persistent BPTT kernel: workgroup %u timed out waiting (code 0x%x, value seen %u); results of that step are invalid",
                   c->h_pf_err[7], c->h_pf_err[4], c->h_pf_err[6]);
         memset(c->h_pf_err + 4, 0, 16);
+        (void)hipMemsetAsync(c->pf_sticky + 4, 0, 16, c->s); // reported: k_rmsprop may apply gradients again
         c->persist_bwd_on = 0; // later steps take the per-level path
         return -3;
     }
@@ -449,7 +433,15 @@ static int check_persist(nvqa_ctx *c)
         set_error("persistent LSTM kernel: workgroup %u timed out waiting (code 0x%x, counter word %ld = (layer,rowblock) %ld step %ld, value seen %u); "
                   "results of that step are invalid", c->h_pf_err[3], c->h_pf_err[0], widx, widx / c->TS, widx % c->TS, c->h_pf_err[2]);
         *c->h_pf_err = 0;
+        (void)hipMemsetAsync(c->pf_sticky, 0, 16, c->s);
         c->persist_on = false; // later steps take the per-level path
+        return -3;
+    }
+    if (c->comm && c->h_dp_status && c->h_dp_status[0] != 0.f) {
+        set_error("data parallel: the persistent LSTM kernel of %d rank(s) timed out in the last step; no rank applied that step's gradients",
+                  (int)c->h_dp_status[0]);
+        c->h_dp_status[0] = 0.f;
+        c->persist_on = false; c->persist_bwd_on = 0; // every rank sees the same sum: all of them leave the persistent path together
         return -3;
     }
     return 0;
@@ -655,105 +647,6 @@ static int wgrad(nvqa_ctx *c, const float *A, int lda, const float *Bm, int ldb,
 // LSTM: shared by arch1 and arch2 (misc/LSTM.lua, misc/LSTM_encoder.lua have the same cell)
 // X0 [TS*B][E] holds the layer-0 inputs; nrows[t] rows are active at step t.
 // ------------------------------------------------------------------------------------
-// The whole forward unroll as one persistent, weight-stationary launch (lstm_persist.h).  Eligible shapes: the two the
-// reference trains (R = 512 with E = 200 [arch1] or E = 512 [arch2]) on a device with one CU per workgroup.
-template <int KA, int KR, int MT, bool BF, bool RAG>
-static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
-{
-    const size_t lds = persist_fwd_lds<KA, KR, MT, BF>();
-    static int resident = -1; // per instantiation: workgroups of this kernel one CU can hold
-    if (resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<KA, KR, MT, BF, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int nb = 0;
-        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<KA, KR, MT, BF, RAG>, NVQA_PF_THREADS, lds));
-        resident = nb;
-    }
-    if (resident < 1 || grid > c->num_cus) { // the workgroups wait for each other: all of them must be resident at once
-        set_error("persistent LSTM kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
-        return -1;
-    }
-    hipLaunchKernelGGL((k_lstm_fwd_persist<KA, KR, MT, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
-    NVQA_HIP(hipGetLastError());
-    return 0;
-}
-
-static int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT), or 0 when the path does not apply
-{
-    const nvqa_dims &d = c->d;
-    if (!c->persist_on || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
-    // (arch2 and equal-length arch1 batches: every row is active whenever any is; ragged arch1 batches: the RAG instance)
-    const int NU = d.R / 16;
-    for (int MT : {4, 8}) { // the smallest row block that still gives every workgroup its own CU
-        const int RB = (d.B + 16 * MT - 1) / (16 * MT);
-        if (d.L * RB * NU <= c->num_cus) return MT;
-    }
-    return 0;
-}
-
-// step-0 slices of the bf16 images of Hs (zeros, or the carried h0 of NVQA_QUIRK_H0): layer = blockIdx.y
-__global__ void k_h0_image(const float *Hs, unsigned short *Hb, size_t layer_stride, int n)
-{
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (i >= n) return;
-    const float2 v = *reinterpret_cast<const float2 *>(Hs + blockIdx.y * layer_stride + i);
-    *reinterpret_cast<unsigned *>(Hb + blockIdx.y * layer_stride + i) = pf_pack_bf16(v.x, v.y);
-}
-
-static int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
-{
-    const nvqa_dims &d = c->d;
-    const int B = d.B, R = d.R, L = d.L, TS = c->TS;
-    PersistFwdArgs a = {};
-    if (c->bf16) { // bf16 images of Hs and U, [L][(TS+1)*B][R] + [L][TS*B][R] (first use of the bf16 instance)
-        const size_t hs = (size_t)(TS + 1) * B * R, us = (size_t)TS * B * R;
-        if (!c->act_b16) NVQA_HIP(hipMalloc((void **)&c->act_b16, (size_t)L * (hs + us) * 2));
-        for (int l = 0; l < L; ++l) { a.Hb[l] = c->act_b16 + l * hs; a.Ub[l] = c->act_b16 + L * hs + l * us; }
-        hipLaunchKernelGGL(k_h0_image, dim3((B * R / 2 + 255) / 256, L), dim3(256), 0, c->s, c->Hs[0], a.Hb[0], hs, B * R);
-        NVQA_HIP(hipGetLastError());
-    }
-    for (int l = 0; l < L; ++l) {
-        a.Wi[l] = c->P + c->lo.w_i2h[l]; a.Wh[l] = c->P + c->lo.w_h2h[l];
-        a.bi[l] = c->P + c->lo.b_i2h[l]; a.bh[l] = c->P + c->lo.b_h2h[l];
-        a.U[l] = c->U[l]; a.Hs[l] = c->Hs[l]; a.Cs[l] = c->Cs[l]; a.Gt[l] = c->Gt[l];
-    }
-    a.X0 = c->X0; a.nrows = c->nrows; a.sort_idx = c->sort_idx;
-    a.B = B; a.R = R; a.E = d.E; a.L = L; a.TS = TS;
-    a.RB = (B + 16 * MT - 1) / (16 * MT); a.NU = R / 16;
-    a.h0_top = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) ? 1 : 0;
-    a.dr = dr;
-    { static const int dbg = [] { const char *e = getenv("NVQA_PF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-    { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
-    a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
-    a.ts = c->pf_ts;
-    const int grid = L * a.RB * a.NU;
-    double flops = 0;
-    for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);
-    ProfScope ps(c, PF_LSTM_FWD, flops, 0);
-    NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s));
-    // ragged arch1 batch (or lengths known only on the device: the dataset route of a ragged dataset): the instance that
-    // skips the MFMAs of row tiles without active rows
-    const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform;
-#define NVQA_PF_GO(KA, MTv, BFv, RAGv) NVQA_TRY((launch_persist_fwd<KA, 512, MTv, BFv, RAGv>(c, a, grid)))
-    if (d.E == 200) { // arch1
-        if (c->bf16) {
-            if (rag) { if (MT == 4) NVQA_PF_GO(200, 4, true, true); else NVQA_PF_GO(200, 8, true, true); }
-            else { if (MT == 4) NVQA_PF_GO(200, 4, true, false); else NVQA_PF_GO(200, 8, true, false); }
-        } else {
-            if (rag) { if (MT == 4) NVQA_PF_GO(200, 4, false, true); else NVQA_PF_GO(200, 8, false, true); }
-            else { if (MT == 4) NVQA_PF_GO(200, 4, false, false); else NVQA_PF_GO(200, 8, false, false); }
-        }
-    } else if (rag) { // (an arch1 model with E = 512)
-        if (c->bf16) { if (MT == 4) NVQA_PF_GO(512, 4, true, true); else NVQA_PF_GO(512, 8, true, true); }
-        else { if (MT == 4) NVQA_PF_GO(512, 4, false, true); else NVQA_PF_GO(512, 8, false, true); }
-    } else {
-        if (c->bf16) { if (MT == 4) NVQA_PF_GO(512, 4, true, false); else NVQA_PF_GO(512, 8, true, false); }
-        else { if (MT == 4) NVQA_PF_GO(512, 4, false, false); else NVQA_PF_GO(512, 8, false, false); }
-    }
-#undef NVQA_PF_GO
-    NVQA_HIP(hipMemcpyAsync(c->h_pf_err, a.err, 16, hipMemcpyDeviceToHost, c->s));
-    return 0;
-}
-
 static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
@@ -831,86 +724,6 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 // and (dX0 != NULL) dX0 holds dL/d(layer-0 input).  Same wavefront as the forward pass, top
 // layer first; the time-batched weight-gradient GEMMs of a layer start on the low-priority
 // bulk stream as soon as that layer's last step is done.
-// BPTT as one persistent launch (lstm_persist_bwd.h): same eligibility as the forward kernel, L <= 2.
-// column tiles (of 16 units) per workgroup of the persistent BPTT kernel: the bf16 weights take half the registers
-static int persist_bwd_ntn(const nvqa_ctx *c) { return c->bf16 && c->d.L > 1 ? 4 : 2; }
-static int persist_bwd_rows(const nvqa_ctx *c, int *RB)
-{
-    const nvqa_dims &d = c->d;
-    // NVQA_PERSIST_BWD: 1 on, 0 off; unset: on for bf16 (0.9 -> 0.x ms), off for f32 (it only ties the per-level kernels)
-    const bool on = c->persist_bwd_on < 0 ? c->bf16 : c->persist_bwd_on > 0;
-    if (!persist_rows(c) || !on || d.L > 2) return 0;
-    const int mtiles = (d.B + 15) / 16, NU = d.R / (16 * persist_bwd_ntn(c)), MT = d.L == 1 || c->bf16 ? 4 : 7;
-    *RB = (mtiles + MT - 1) / MT;
-    if ((2 * d.L - 1) * *RB * NU > c->num_cus || c->num_cus < 256 || (2 * d.L - 1) * *RB > 8 * (32 / NU)) return 0;
-    return MT;
-}
-
-template <int GK, int MT, int NTN, bool BF, bool RAG>
-static int launch_persist_bwd(nvqa_ctx *c, const PersistBwdArgs &a, int grid)
-{
-    const size_t lds = PersistBwdGeom<MT, NTN>::LDS_BYTES;
-    static int resident = -1;
-    if (resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_bwd_persist<GK, MT, NTN, BF, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int nb = 0;
-        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_bwd_persist<GK, MT, NTN, BF, RAG>, NVQA_PF_THREADS, lds));
-        resident = nb;
-    }
-    if (resident < 1 || grid > c->num_cus) {
-        set_error("persistent BPTT kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
-        return -1;
-    }
-    hipLaunchKernelGGL((k_lstm_bwd_persist<GK, MT, NTN, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
-    NVQA_HIP(hipGetLastError());
-    return 0;
-}
-
-static int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
-{
-    const nvqa_dims &d = c->d;
-    const int B = d.B, R = d.R, L = d.L, TS = c->TS;
-    PersistBwdArgs a = {};
-    for (int l = 0; l < L; ++l) {
-        a.Wh[l] = c->P + c->lo.w_h2h[l]; a.Wi[l] = c->P + c->lo.w_i2h[l];
-        a.Gt[l] = c->Gt[l]; a.Cs[l] = c->Cs[l];
-        a.Pup[l] = l + 1 < L ? c->pb_pup + (size_t)l * TS * B * R : nullptr;
-    }
-    a.dCT = c->dCT; a.dHT = c->dHT;
-    a.nrows = c->nrows; a.sort_idx = c->sort_idx;
-    a.tlast = d.arch == NVQA_ARCH2 ? c->tinfo + 1 : nullptr;
-    a.B = B; a.R = R; a.L = L; a.TS = TS; a.RB = RB; a.NU = R / (16 * persist_bwd_ntn(c));
-    a.dr = dr;
-    if (c->bf16) { // bf16 image of dG, [L][TS*B][4R] (first use of the bf16 instance)
-        const size_t gs = (size_t)TS * B * 4 * R;
-        if (!c->dg_b16) NVQA_HIP(hipMalloc((void **)&c->dg_b16, (size_t)L * gs * 2));
-        for (int l = 0; l < L; ++l) a.Gb[l] = c->dg_b16 + l * gs;
-    }
-    { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
-    { static const int dbg = [] { const char *e = getenv("NVQA_PB_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-    const size_t n_rec = (size_t)L * RB * TS, n_up = (size_t)L * RB * a.NU * TS;
-    if (n_rec + n_up + 4 > c->pb_cnt_words) { set_error("persistent BPTT: counter block too small"); return -1; }
-    a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = c->pb_cnt + c->pb_cnt_words - 4;
-    a.bias_part = c->pb_bias; // [L][RB][4R]: the kernel also leaves the LSTM bias gradients (column sums of dG) per row block
-    c->pb_bias_rb = c->pb_bias ? RB : 0;
-    a.ts = c->pf_ts + 1024;
-    const int grid = 256; // 8 XCDs x 32 slots (lstm_persist_bwd.h maps groups to XCDs); (2L-1) * RB * NU of them have work
-    double flops = 0;
-    for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * R * ((double)(TS - 1) + (l + 1 < L ? TS : 0));
-    ProfScope ps(c, PF_LSTM_BWD, flops, 0);
-    NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
-    const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform; // as in lstm_forward_persist
-    if (c->bf16) {
-        if (L == 1) { if (rag) NVQA_TRY((launch_persist_bwd<16, 4, 2, true, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<16, 4, 2, true, false>(c, a, grid))); }
-        else { if (rag) NVQA_TRY((launch_persist_bwd<16, 4, 4, true, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<16, 4, 4, true, false>(c, a, grid))); }
-    } else {
-        if (MT == 4) { if (rag) NVQA_TRY((launch_persist_bwd<32, 4, 2, false, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<32, 4, 2, false, false>(c, a, grid))); }
-        else { if (rag) NVQA_TRY((launch_persist_bwd<32, 7, 2, false, true>(c, a, grid))); else NVQA_TRY((launch_persist_bwd<32, 7, 2, false, false>(c, a, grid))); }
-    }
-    NVQA_HIP(hipMemcpyAsync(c->h_pf_err + 4, a.err, 16, hipMemcpyDeviceToHost, c->s));
-    return 0;
-}
-
 static int lstm_backward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
@@ -1323,8 +1136,10 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, R, B, R, A),
                                        EpiHead2{c->dHT + (size_t)(L - 1) * B * R, R, dr})));
     }
-    if (c->quirks & NVQA_QUIRK_H0) // the aliased h0 tensor now holds THIS step's gradient: the step-1 dW_h2h sees it
+    if (c->quirks & NVQA_QUIRK_H0) { // the aliased h0 tensor now holds THIS step's gradient: the step-1 dW_h2h sees it
         NVQA_HIP(hipMemcpyAsync(c->Hs[L - 1], c->dHT + (size_t)(L - 1) * B * R, (size_t)B * R * 4, hipMemcpyDeviceToDevice, c->s));
+        NVQA_TRY(persist_reimage_h0_top(c)); // ... and so does the bf16 image the weight-gradient kernel stages from
+    }
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
     NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr));
@@ -1352,6 +1167,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
 static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
 {
     const Drop dr = mkdrop(dropout, true);
+    if (c->comm) NVQA_HIP(hipMemsetAsync(c->dp_status, 0, 16, c->s));
     if (c->d.arch == NVQA_ARCH1) {
         NVQA_TRY(arch1_forward(c, dr, true, false));
         NVQA_TRY(arch1_backward(c, dr));
@@ -1572,14 +1388,14 @@ extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps
         const size_t n4 = c->lo.total / 4; // every tensor size is a multiple of 4 (check_dims)
         hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
                            reinterpret_cast<const float4 *>(c->G), reinterpret_cast<float4 *>(c->M2), n4, lr, alpha,
-                           eps, wd, clamp, inv_world * c->gscale[0]);
+                           eps, wd, clamp, inv_world * c->gscale[0], c->pf_sticky, c->comm ? c->dp_status : (const float *)nullptr);
     } else { // -lr_scale of 003_train_ae_based_wp.lua:344: encoder / embedding gradients scaled before the clamp
         size_t off = 0;
         for (int sgm = 0; sgm < 3; ++sgm) {
             const size_t n4 = c->lo.seg[sgm] / 4;
             hipLaunchKernelGGL(k_rmsprop, dim3(1024), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P + off),
                                reinterpret_cast<const float4 *>(c->G + off), reinterpret_cast<float4 *>(c->M2 + off), n4,
-                               lr, alpha, eps, wd, clamp, inv_world * c->gscale[sgm]);
+                               lr, alpha, eps, wd, clamp, inv_world * c->gscale[sgm], c->pf_sticky, c->comm ? c->dp_status : (const float *)nullptr);
             off += c->lo.seg[sgm];
         }
     }
@@ -1783,6 +1599,15 @@ static void comm_destroy(nvqa_ctx *c)
 static int reduce_join(nvqa_ctx *c)
 {
     if (!c->comm) return 0;
+    {   // did any rank's persistent kernel give up in this step?  dp_status[0] was set by the err latches behind the launches
+        // (persist_fwd.hip); its sum over the ranks makes every rank's k_rmsprop skip the update together.
+        NVQA_HIP(hipEventRecord(c->evSeg[0], c->s));
+        NVQA_HIP(hipStreamWaitEvent(c->sc, c->evSeg[0], 0));
+        const Rccl *r = rccl_of(c);
+        const int rc = r->AllReduce(c->dp_status, c->dp_status, 4, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
+        if (rc) { set_error("ncclAllReduce (status): %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
+        NVQA_HIP(hipMemcpyAsync(c->h_dp_status, c->dp_status, 16, hipMemcpyDeviceToHost, c->sc));
+    }
     NVQA_HIP(hipEventRecord(c->evComm, c->sc));
     NVQA_HIP(hipStreamWaitEvent(c->s, c->evComm, 0));
     return 0;

@@ -131,7 +131,9 @@ struct nvqa_ctx {
     int pb_bias_rb = 0;           // row blocks of this step's partial sums (0: none: lstm_wgrads runs the column-sum kernels)
     unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd.h)
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
-    unsigned *h_pf_err = nullptr; // pinned copies of the err records (forward: words 0-3, BPTT: words 4-7)
+    unsigned *h_pf_err = nullptr; // pinned copies of the sticky err records (forward: words 0-3, BPTT: words 4-7)
+    unsigned *pf_sticky = nullptr; // device: first failure of a persistent kernel since the host last looked (persist_fwd.hip: k_err_latch)
+    float *dp_status = nullptr, *h_dp_status = nullptr; // data parallel: [0] = ranks whose persistent kernel gave up in this step (summed by the exchange)
     int persist_bwd_on = -1;       // BPTT as one persistent launch (lstm_persist_bwd.h)
     unsigned *pb_cnt = nullptr;   // its counters + err record
     size_t pb_cnt_words = 0;

@@ -1,0 +1,142 @@
+// persist_fwd.hip -- launcher of the persistent forward LSTM kernel (lstm_persist.h), its own translation unit.
+#include <stdlib.h>
+#include <string.h>
+
+#include "lstm_persist.h"
+#include "persist_host.h"
+
+namespace nvqa {
+
+// The err record of a launch lives in the counter block, which the memset in front of EVERY launch clears: a step that
+// timed out would be overwritten by the next clean one before an asynchronous trainer loop reads it.  So each launch is
+// followed by this latch: the FIRST failure is copied into a sticky record that only the host clears, once it has reported
+// it (check_persist), and k_rmsprop refuses to apply gradients while a record is set.  dp_status[0] (data parallel) is
+// summed over the ranks at the end of the step, so that every rank skips the update if any rank's kernel gave up.
+__global__ void k_err_latch(const unsigned *err, unsigned *sticky, float *dp_status)
+{
+    if (threadIdx.x == 0 && err[0] != 0) {
+        if (sticky[0] == 0) { sticky[1] = err[1]; sticky[2] = err[2]; sticky[3] = err[3]; sticky[0] = err[0]; }
+        if (dp_status) dp_status[0] = 1.0f;
+    }
+}
+int persist_latch_err(nvqa_ctx *c, const unsigned *err, int off)
+{
+    hipLaunchKernelGGL(k_err_latch, dim3(1), dim3(64), 0, c->s, err, c->pf_sticky + off, c->comm ? c->dp_status : (float *)nullptr);
+    NVQA_HIP(hipGetLastError());
+    NVQA_HIP(hipMemcpyAsync(c->h_pf_err + off, c->pf_sticky + off, 16, hipMemcpyDeviceToHost, c->s));
+    return 0;
+}
+
+// The whole forward unroll as one persistent, weight-stationary launch (lstm_persist.h).  Eligible shapes: the two the
+// reference trains (R = 512 with E = 200 [arch1] or E = 512 [arch2]) on a device with one CU per workgroup.
+template <int KA, int KR, int MT, bool BF, bool RAG>
+static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
+{
+    const size_t lds = persist_fwd_lds<KA, KR, MT, BF>();
+    static int resident = -1; // per instantiation: workgroups of this kernel one CU can hold
+    if (resident < 0) {
+        NVQA_HIP(hipFuncSetAttribute((const void *)k_lstm_fwd_persist<KA, KR, MT, BF, RAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nb = 0;
+        NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lstm_fwd_persist<KA, KR, MT, BF, RAG>, NVQA_PF_THREADS, lds));
+        resident = nb;
+    }
+    if (resident < 1 || grid > c->num_cus) { // the workgroups wait for each other: all of them must be resident at once
+        set_error("persistent LSTM kernel cannot be co-resident (%d workgroups, %d CUs, %d per CU)", grid, c->num_cus, resident);
+        return -1;
+    }
+    hipLaunchKernelGGL((k_lstm_fwd_persist<KA, KR, MT, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT), or 0 when the path does not apply
+{
+    const nvqa_dims &d = c->d;
+    if (!c->persist_on || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
+    // (arch2 and equal-length arch1 batches: every row is active whenever any is; ragged arch1 batches: the RAG instance)
+    const int NU = d.R / 16;
+    for (int MT : {4, 8}) { // the smallest row block that still gives every workgroup its own CU
+        const int RB = (d.B + 16 * MT - 1) / (16 * MT);
+        if (d.L * RB * NU <= c->num_cus) return MT;
+    }
+    return 0;
+}
+
+// step-0 slices of the bf16 images of Hs (zeros, or the carried h0 of NVQA_QUIRK_H0): layer = blockIdx.y
+__global__ void k_h0_image(const float *Hs, unsigned short *Hb, size_t layer_stride, int n)
+{
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float2 v = *reinterpret_cast<const float2 *>(Hs + blockIdx.y * layer_stride + i);
+    *reinterpret_cast<unsigned *>(Hb + blockIdx.y * layer_stride + i) = pf_pack_bf16(v.x, v.y);
+}
+
+// NVQA_QUIRK_H0 + bf16: arch2_backward copies THIS step's dL/dh into slice 0 of Hs[L-1] (the aliased tensor the step-1
+// clone's accGradParameters reads, Encoder_lstm.lua:238-239); the bf16 image of that slice, which the weight-gradient kernel
+// stages from, was made at forward time from the previous step's gradient: refresh it.
+int persist_reimage_h0_top(nvqa_ctx *c)
+{
+    if (!c->act_b16 || !c->img_fwd_valid) return 0;
+    const nvqa_dims &d = c->d;
+    const size_t hs = (size_t)(c->TS + 1) * d.B * d.R;
+    hipLaunchKernelGGL(k_h0_image, dim3((d.B * d.R / 2 + 255) / 256, 1), dim3(256), 0, c->s, c->Hs[d.L - 1], c->act_b16 + (size_t)(d.L - 1) * hs, hs, d.B * d.R);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
+{
+    const nvqa_dims &d = c->d;
+    const int B = d.B, R = d.R, L = d.L, TS = c->TS;
+    PersistFwdArgs a = {};
+    if (c->bf16) { // bf16 images of Hs and U, [L][(TS+1)*B][R] + [L][TS*B][R] (first use of the bf16 instance)
+        const size_t hs = (size_t)(TS + 1) * B * R, us = (size_t)TS * B * R;
+        if (!c->act_b16) NVQA_HIP(hipMalloc((void **)&c->act_b16, (size_t)L * (hs + us) * 2));
+        for (int l = 0; l < L; ++l) { a.Hb[l] = c->act_b16 + l * hs; a.Ub[l] = c->act_b16 + L * hs + l * us; }
+        hipLaunchKernelGGL(k_h0_image, dim3((B * R / 2 + 255) / 256, L), dim3(256), 0, c->s, c->Hs[0], a.Hb[0], hs, B * R);
+        NVQA_HIP(hipGetLastError());
+    }
+    for (int l = 0; l < L; ++l) {
+        a.Wi[l] = c->P + c->lo.w_i2h[l]; a.Wh[l] = c->P + c->lo.w_h2h[l];
+        a.bi[l] = c->P + c->lo.b_i2h[l]; a.bh[l] = c->P + c->lo.b_h2h[l];
+        a.U[l] = c->U[l]; a.Hs[l] = c->Hs[l]; a.Cs[l] = c->Cs[l]; a.Gt[l] = c->Gt[l];
+    }
+    a.X0 = c->X0; a.nrows = c->nrows; a.sort_idx = c->sort_idx;
+    a.B = B; a.R = R; a.E = d.E; a.L = L; a.TS = TS;
+    a.RB = (B + 16 * MT - 1) / (16 * MT); a.NU = R / 16;
+    a.h0_top = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) ? 1 : 0;
+    a.dr = dr;
+    { static const int dbg = [] { const char *e = getenv("NVQA_PF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+    { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
+    a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
+    a.ts = c->pf_ts;
+    const int grid = L * a.RB * a.NU;
+    double flops = 0;
+    for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);
+    ProfScope ps(c, PF_LSTM_FWD, flops, 0);
+    NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s));
+    // ragged arch1 batch (or lengths known only on the device: the dataset route of a ragged dataset): the instance that
+    // skips the MFMAs of row tiles without active rows
+    const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform;
+#define NVQA_PF_GO(KA, MTv, BFv, RAGv) NVQA_TRY((launch_persist_fwd<KA, 512, MTv, BFv, RAGv>(c, a, grid)))
+    if (d.E == 200) { // arch1
+        if (c->bf16) {
+            if (rag) { if (MT == 4) NVQA_PF_GO(200, 4, true, true); else NVQA_PF_GO(200, 8, true, true); }
+            else { if (MT == 4) NVQA_PF_GO(200, 4, true, false); else NVQA_PF_GO(200, 8, true, false); }
+        } else {
+            if (rag) { if (MT == 4) NVQA_PF_GO(200, 4, false, true); else NVQA_PF_GO(200, 8, false, true); }
+            else { if (MT == 4) NVQA_PF_GO(200, 4, false, false); else NVQA_PF_GO(200, 8, false, false); }
+        }
+    } else if (rag) { // (an arch1 model with E = 512)
+        if (c->bf16) { if (MT == 4) NVQA_PF_GO(512, 4, true, true); else NVQA_PF_GO(512, 8, true, true); }
+        else { if (MT == 4) NVQA_PF_GO(512, 4, false, true); else NVQA_PF_GO(512, 8, false, true); }
+    } else {
+        if (c->bf16) { if (MT == 4) NVQA_PF_GO(512, 4, true, false); else NVQA_PF_GO(512, 8, true, false); }
+        else { if (MT == 4) NVQA_PF_GO(512, 4, false, false); else NVQA_PF_GO(512, 8, false, false); }
+    }
+#undef NVQA_PF_GO
+    NVQA_TRY(persist_latch_err(c, a.err, 0));
+    return 0;
+}
+
+} // namespace nvqa

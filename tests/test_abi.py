@@ -63,3 +63,57 @@ def test_lua_cdef_declares_every_header_function():
     names = set(re.findall(r"\b(nvqa_[a-z0-9_]+)\s*\(", hdr))
     missing = sorted(n for n in names if not re.search(r"\b%s\s*\(" % n, lua))
     assert not missing, missing
+
+
+def _prototypes(text):
+    """{name: normalised prototype} of every nvqa_* function declared in a block of C declarations: comments stripped,
+    white space collapsed, parameter NAMES dropped (the header and the cdef may call them differently), types kept."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(nvqa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        ret = re.sub(r"\b(extern|NVQA_API)\b", "", ret)
+
+        def norm_type(t):
+            t = re.sub(r"\s+", " ", t).strip()
+            t = re.sub(r"\s*\*\s*", "*", t)
+            return t
+
+        params = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            arr = re.search(r"\[(\d*)\]\s*$", a)  # `size_t out[3]` is a pointer parameter
+            a = re.sub(r"\[\d*\]\s*$", "", a).strip()
+            mm = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)$", a, flags=re.S)
+            ty = mm.group(1) if mm and mm.group(1).strip() and mm.group(2) not in ("int", "float", "double", "void", "size_t", "int32_t", "int64_t", "uint64_t", "char") else a
+            ty = norm_type(ty) + ("*" if arr else "")
+            params.append(ty)
+        out[name] = norm_type(ret) + " " + name + "(" + ", ".join(params) + ")"
+    return out
+
+
+def test_lua_cdef_prototypes_equal_the_header():
+    """Every prototype of novel-vqa_amd/lua/nvqa_ffi.lua's ffi.cdef -- return type and every parameter type, in order -- is
+    the one include/nvqa.h declares, and the two POD structs have the same fields.  (LuaJIT binds by this text alone: a
+    drifted cdef would call the library with a wrong stack layout.)"""
+    hdr = open(os.path.join(ROOT, "include", "nvqa.h")).read()
+    lua = open(os.path.join(ROOT, "novel-vqa_amd", "lua", "nvqa_ffi.lua")).read()
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S).group(1)
+    ph, pl = _prototypes(hdr), _prototypes(cdef)
+    assert len(ph) >= 30 and set(ph) == set(pl), sorted(set(ph) ^ set(pl))
+    diff = {n: (ph[n], pl[n]) for n in ph if ph[n] != pl[n]}
+    assert not diff, diff
+
+    def struct_fields(text, name):
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        body = re.search(r"struct\s+%s\s*\{(.*?)\}" % name, text, flags=re.S).group(1)
+        fields = []
+        for decl in [d.strip() for d in body.split(";") if d.strip()]:
+            ty, names = re.match(r"^(.*?)\s+([A-Za-z0-9_,\s]+)$", decl, flags=re.S).groups()
+            fields += [(re.sub(r"\s+", " ", ty), n.strip()) for n in names.split(",")]
+        return fields
+    for st in ("nvqa_dims", "nvqa_dropout"):
+        assert struct_fields(hdr, st) == struct_fields(cdef, st), st
