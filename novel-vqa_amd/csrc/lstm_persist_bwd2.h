@@ -340,7 +340,13 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             }
             const size_t srow_g = (size_t)s * B + grow;
             const unsigned uo = (unsigned)((srow_g * R + u0 + 4 * eq) * 4);
-            if (is_up) { // ship the product; the cell of layer l adds it
+            if (is_up) {
+                // ship the product, already multiplied by Dropout' of the layer boundary (x 0 or x 1/(1-p): exact, so the cell of
+                // layer l adds the same value it would have formed itself).  The mask hash is a third of the cell backward's
+                // vector instructions; the UP role's epilogue is otherwise one store, and REC(l) sets the pace of the launch.
+                const uint64_t didx = ((((uint64_t)l) * B + esi[H][e]) * TS + s) * R + u0 + 4 * eq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= a.dr.scale(NVQA_SITE_LSTM, didx + j);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v), r_p, uo, 0, 16);
                 continue;
             }
@@ -350,11 +356,9 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             if (grow < nr) {
                 const pf_f32x4 dc0 = *dcp;
                 const pf_f32x4 ig = e_ig[e], fg = e_fg[e], og = e_og[e], gg = e_gg[e], cc = dcp[1], cp = e_cp[e], v2 = e_v2[e], hx = e_hx[e];
-                const uint64_t didx = ((((uint64_t)l) * B + esi[H][e]) * TS + s) * R + u0 + 4 * eq;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float dsc = has_up ? a.dr.scale(NVQA_SITE_LSTM, didx + j) : 0.f;
-                    const float dh = v[j] + dsc * v2[j] + hx[j];
+                    const float dh = v[j] + v2[j] + hx[j]; // v2: the UP tile, Dropout' applied by its producer (zeros without one)
                     const float tc = pf_tanh(cc[j]);
                     const float dcv = dc0[j] + dh * og[j] * (1.0f - tc * tc);
                     dgi[j] = dcv * gg[j] * ig[j] * (1.0f - ig[j]);
@@ -472,8 +476,11 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             // A tile's fragments are refilled right after its tile-group (from the next group of the chunk, or -- last group --
             // from chunk q+1, which the barrier behind tile-group TGB has published); the other tiles' MFMAs cover the read.
             constexpr int NW = BF ? 1 : 4, NTG = GPC * MT, G = NTG * NW;     // gaps per chunk
+            constexpr int QS = 2;                                            // iteration at whose barrier the previous half-step is signalled
             constexpr int TGB = (GPC - 1) * MT;                              // the barrier follows this tile-group
             constexpr int GB = (TGB + 1) * NW;                               // gaps in front of the barrier
+            constexpr int GC = GB > NW ? GB - NW : GB;                       // ... that carry LDS writes: the last tile-group in front of the
+                                                                             // barrier carries none, so that lgkmcnt(0) there is met on arrival
             auto gap = [&](auto g_tag) {
                 constexpr int g = decltype(g_tag)::value;
                 // loads of chunk q+D: spread over all gaps; LDS writes of chunk q+1: over the gaps in front of the barrier
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
                 [&]<int... J>(std::integer_sequence<int, J...>) { (ld1(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, NLDL>{});
                 auto cm1 = [&](auto j_tag) {
                     constexpr int J = decltype(j_tag)::value;
-                    if constexpr ((J * GB) / NLDC == g) {
+                    if constexpr ((J * GC) / NLDC == g) {
                         if constexpr (cm_own) commit_piece(HT, std::integral_constant<int, SETC>{}, nst, j_tag, std::integral_constant<int, J + 1>{});
                         else commit_piece(HNT, std::integral_constant<int, SETC>{}, nst, j_tag, std::integral_constant<int, J + 1>{});
                     }
@@ -506,17 +513,26 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
                     };
                     [&]<int... W>(std::integer_sequence<int, W...>) { (quarter(std::integral_constant<int, W>{}), ...); }(std::make_integer_sequence<int, NW>{});
                     if constexpr (TG == TGB) {
-                        if constexpr (q == 0) { // the previous half-step's write-through stores: older than the loads issued in this iteration so far
+                        // The previous half-step's write-through stores are drained and signalled at the barrier of iteration QS
+                        // (their round trip to memory is longer than a chunk: drained at the first barrier the waves parked there
+                        // for ~1 us per half-step; the consumers have a whole half-step of slack).  Younger than those stores are
+                        // exactly: the NLD loads of every iteration before QS, the cell operands requested at iteration 0 (5 per
+                        // item) and the loads of this iteration issued so far -- a counted wait leaves them in flight.
+                        if constexpr (q == QS) {
                             constexpr int issued = [] { int c = 0; for (int j = 0; j < NLDL; ++j) c += (j * G) / NLDL < GB ? 1 : 0; return c; }();
-                            if (pub >= 0) pb_wait_vmcnt<issued>();
+                            constexpr int younger = QS * NLD + 5 * NE + issued;
+                            static_assert(QS + D < NT, "the iterations up to QS request chunks of this half-step");
+                            if (pub >= 0) pb_wait_vmcnt<(younger < 63 ? younger : 63)>();
                         }
                         __syncthreads();
-                        if constexpr (q == 0) {
+                        if constexpr (q == QS) {
                             if (pub >= 0) {
                                 if (tid == 0) __hip_atomic_fetch_add(own_word(__builtin_amdgcn_readfirstlane(pub)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 pub = -1;
                             }
-                            // this half-step's cell operands: requested behind the drain point, a product ahead of their use
+                        }
+                        if constexpr (q == 0) {
+                            // this half-step's cell operands, a product ahead of their use
 #pragma unroll
                             for (int e = 0; e < NE; ++e) fetch(H, s, e);
                         }

@@ -1554,6 +1554,20 @@ extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world %d/%d", rank, world); return -1; }
     if (c->comm) { set_error("nvqa_comm_init: the context already has a communicator"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
+    {   // Co-residency policy.  The persistent BPTT kernel needs all its workgroups resident at once
+        // (240 of the 256 CUs in f32, 192 in bf16) while the multimodal all-reduce travels underneath it on the communication
+        // stream; a collective kernel holds one CU per channel while it runs.  The library therefore leaves the collective
+        // NVQA_COMM_CUS compute units (default 16) and, unless the caller has set it, caps RCCL's channels at that number
+        // BEFORE the communicator is created; persist_bwd_rows() refuses the persistent path when its grid would not leave
+        // them free.  (The forward kernel takes every CU: no exchange is in flight then -- reduce_join ends the step.)
+        const char *e = getenv("NVQA_COMM_CUS");
+        c->comm_cus = e ? atoi(e) : 16;
+        if (c->comm_cus > 0) {
+            char buf[16];
+            snprintf(buf, sizeof(buf), "%d", c->comm_cus);
+            setenv("NCCL_MAX_NCHANNELS", buf, 0);
+        }
+    }
     const Rccl *r = load_rccl();
     if (!r) return -1;
     Id128 idv;

@@ -150,6 +150,7 @@ struct nvqa_ctx {
     void *comm = nullptr;
     const void *rccl = nullptr; // the collective library's entry points this communicator came from (nvqa_api.hip)
     int rank = 0, world = 1;
+    int comm_cus = 0;           // compute units left to the collective while a persistent kernel runs (nvqa_comm_init)
 
     // profiling
     bool prof_on = false;

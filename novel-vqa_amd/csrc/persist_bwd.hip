@@ -36,6 +36,8 @@ int persist_bwd_rows(const nvqa_ctx *c, int *RB)
     const int mtiles = (d.B + 15) / 16, NU = d.R / (16 * persist_bwd_ntn(c)), MT = d.L == 1 || c->bf16 ? 4 : 7;
     *RB = (mtiles + MT - 1) / MT;
     if ((2 * d.L - 1) * *RB * NU > c->num_cus || c->num_cus < 256 || (2 * d.L - 1) * *RB > 8 * (32 / NU)) return 0;
+    // data parallel: an all-reduce is in flight during BPTT; its kernel keeps the CUs nvqa_comm_init left it
+    if (c->comm && (2 * d.L - 1) * *RB * NU + c->comm_cus > c->num_cus) return 0;
     return MT;
 }
 

@@ -8,6 +8,11 @@
 // zero or two times, a missing event edge or a clamp applied before the mean all break that.
 // NCCL_SHIM_DELAY_US stretches every all-reduce (bounded busy wait at the start of the kernel), so that a consumer
 // that does not wait for the communication stream reads data the shim has not touched yet.
+// NCCL_SHIM_CUS = n gives the all-reduce the FOOTPRINT of a real collective kernel: n workgroups, each claiming a whole
+// compute unit (the full 160 KB of LDS, so nothing can share it), held for the time the slice would take over one xGMI
+// link pair (bytes / 150 GB/s, on top of NCCL_SHIM_DELAY_US).  The persistent LSTM kernels of libnvqa need ALL their
+// workgroups resident at once; with this mode tests/test_gpu_dp_fullsize.py runs them next to a collective that holds
+// CUs during the backward pass, which no one-GPU box can do with librccl itself.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -25,6 +30,34 @@ __global__ void k_scale(const float *send, float *recv, size_t n, float world, l
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         recv[i] = world * send[i];
+}
+// the footprint form: every workgroup owns its CU (dynamic LDS = the CU's whole 160 KB) until `hold_ticks` have passed
+__global__ void k_scale_cu(const float *send, float *recv, size_t n, float world, long hold_ticks)
+{
+    extern __shared__ float hog[];
+    const long t0 = (long)wall_clock64();
+    if (threadIdx.x == 0) hog[0] = 0.f; // (the allocation is what matters)
+    // (16-byte accesses, four in flight per thread: a handful of workgroups must move the slice faster than the link would)
+    const size_t n4 = ((reinterpret_cast<uintptr_t>(send) | reinterpret_cast<uintptr_t>(recv)) & 15) == 0 ? n / 4 : 0;
+    const float4 *s4 = reinterpret_cast<const float4 *>(send);
+    float4 *r4 = reinterpret_cast<float4 *>(recv);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
+        v0.x *= world; v0.y *= world; v0.z *= world; v0.w *= world;
+        v1.x *= world; v1.y *= world; v1.z *= world; v1.w *= world;
+        v2.x *= world; v2.y *= world; v2.z *= world; v2.w *= world;
+        v3.x *= world; v3.y *= world; v3.z *= world; v3.w *= world;
+        r4[i] = v0; r4[i + stride] = v1; r4[i + 2 * stride] = v2; r4[i + 3 * stride] = v3;
+    }
+    for (; i < n4; i += stride) {
+        float4 v = s4[i];
+        v.x *= world; v.y *= world; v.z *= world; v.w *= world;
+        r4[i] = v;
+    }
+    for (size_t k = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) recv[k] = world * send[k];
+    while ((long)wall_clock64() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(32);
 }
 } // namespace
 
@@ -44,6 +77,16 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
     c->elems += (double)count;
     const char *e = getenv("NCCL_SHIM_DELAY_US");
     const long ticks = e ? atol(e) * 100 : 0;
+    const char *ec = getenv("NCCL_SHIM_CUS");
+    const int cus = ec ? atoi(ec) : 0;
+    if (cus > 0) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void *)k_scale_cu, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        long hold = ticks + (long)((double)count * 4.0 / 150e9 * 1e8); // 100 MHz ticks of the slice at 150 GB/s
+        hipLaunchKernelGGL(k_scale_cu, dim3(cus > 256 ? 256 : cus), dim3(256), 160 * 1024, s, (const float *)send, (float *)recv, count,
+                           (float)c->world, hold > 500000 ? 500000 : hold);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     hipLaunchKernelGGL(k_scale, dim3(256), dim3(256), 0, s, (const float *)send, (float *)recv, count, (float)c->world,
                        ticks > 500000 ? 500000 : ticks); // at most 5 ms
     return hipGetLastError() == hipSuccess ? 0 : 1;
