@@ -86,10 +86,46 @@ __global__ void k_fc_finish(const float *slabs, int S, int M, int N, const float
     out[i] = fmaxf(s + bias[i % N], 0.0f);
 }
 
-// loadim (001_prepro_img_vgg.lua:47-71): bilinear scale to 224x224 ignoring aspect, x255, RGB -> BGR,
-// per-channel mean subtraction.  in [n][3][H][W] RGB in [0,1]; out [n][3][224][224] (BGR planes).
-// The exact interpolation of Torch's image.scale is not pinned by the reference; align-corners
-// bilinear is used and said so in DESIGN.md.
+// One output sample of Torch's image.scale 1-D pass (torch/image generic/image.c: image_(Main_scaleLinear_rowcol); the
+// `image` rock is third-party and absent from the reference checkout -- the algorithm is its published one, PARITY UNPINNED):
+//   dst_len > src_len: linear interpolation with step (src_len - 1) / (dst_len - 1), last sample copied;
+//   dst_len < src_len: area average over [di s, (di + 1) s), s = src_len / dst_len, end samples weighted by coverage;
+//   equal: copy.
+// `at(i)` returns source sample i.  Unfused float operations in the source's order (__f*_rn are never contracted).
+template <class F> __device__ __forceinline__ float scale1d(F at, int src_len, int dst_len, int di)
+{
+    if (dst_len > src_len) {
+        if (di == dst_len - 1) return at(src_len - 1);
+        if (src_len == 1) return at(0);
+        const float scale = __fdiv_rn((float)(src_len - 1), (float)(dst_len - 1));
+        float si_f = __fmul_rn((float)di, scale);
+        const int si_i = (int)si_f;
+        si_f = __fsub_rn(si_f, (float)si_i);
+        return __fadd_rn(__fmul_rn(__fsub_rn(1.0f, si_f), at(si_i)), __fmul_rn(si_f, at(si_i + 1)));
+    }
+    if (dst_len < src_len) {
+        const float scale = __fdiv_rn((float)src_len, (float)dst_len);
+        float si0_f = __fmul_rn((float)di, scale), si1_f = __fmul_rn((float)(di + 1), scale);
+        const int si0_i = (int)si0_f, si1_i = (int)si1_f;
+        si0_f = __fsub_rn(si0_f, (float)si0_i);
+        si1_f = __fsub_rn(si1_f, (float)si1_i);
+        float acc = __fmul_rn(__fsub_rn(1.0f, si0_f), at(si0_i)), n = __fsub_rn(1.0f, si0_f);
+        for (int si = si0_i + 1; si < si1_i; ++si) {
+            acc = __fadd_rn(acc, at(si));
+            n = __fadd_rn(n, 1.0f);
+        }
+        if (si1_i < src_len) {
+            acc = __fadd_rn(acc, __fmul_rn(si1_f, at(si1_i)));
+            n = __fadd_rn(n, si1_f);
+        }
+        return __fdiv_rn(acc, n);
+    }
+    return at(di);
+}
+
+// loadim (001_prepro_img_vgg.lua:47-71): image.scale to S x S ignoring aspect (rows first, then columns: the vertical pass
+// runs over horizontally scaled rows, recomputed here per output pixel in the same order), x255, RGB -> BGR, per-channel
+// mean subtraction.  in [n][3][H][W] RGB in [0,1]; out [n][3][S][S] (BGR planes).
 __global__ void k_vgg_preprocess(const float *in, int n, int H, int W, int S, float *out)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,15 +135,13 @@ __global__ void k_vgg_preprocess(const float *in, int n, int H, int W, int S, fl
     const size_t img = i / ((size_t)3 * S * S);
     const int src_c = 2 - c; // output plane 0 = B = input plane 2
     const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
-    const float fy = S > 1 ? (float)y * (float)(H - 1) / (float)(S - 1) : 0.f;
-    const float fx = S > 1 ? (float)x * (float)(W - 1) / (float)(S - 1) : 0.f;
-    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-    const float wy = fy - (float)y0, wx = fx - (float)x0;
     const float *p = in + (img * 3 + src_c) * (size_t)H * W;
-    const float v = (1.f - wy) * ((1.f - wx) * p[(size_t)y0 * W + x0] + wx * p[(size_t)y0 * W + x1]) +
-                    wy * ((1.f - wx) * p[(size_t)y1 * W + x0] + wx * p[(size_t)y1 * W + x1]);
-    out[i] = v * 255.0f - mean;
+    auto hrow = [&](int r) { // sample x of source row r scaled to width S
+        const float *row = p + (size_t)r * W;
+        return scale1d([&](int k) { return row[k]; }, W, S, x);
+    };
+    const float v = scale1d(hrow, H, S, y);
+    out[i] = __fsub_rn(__fmul_rn(v, 255.0f), mean);
 }
 
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgConv;   // C_out >= 128: 8 waves of 32 x 64, 16x16x4 MFMA (tools/kbench3: 117 vs 95 TF for the K-contiguous x K-contiguous form)

@@ -125,26 +125,85 @@ int oracle_vgg16_fc7(int width_div, int hw, const float *flat, const float *imag
     return 0;
 }
 
-/* loadim (001_prepro_img_vgg.lua:47-71) minus the file decode: rgb n x 3 x H x W in [0,1] ->
- * n x 3 x S x S BGR planes, x255, mean-subtracted.  Align-corners bilinear (Torch's image.scale
- * interpolation is not pinned by the reference). */
+/* image.scale(src, width, height) in its default 'bilinear' mode (001_prepro_img_vgg.lua:50).  The `image` rock is NOT in
+ * /root/reference (third-party, unpinned: SURVEY.md section 2 row 14); this restates the algorithm of its published source
+ * (torch/image, generic/image.c: image_(Main_scaleBilinear) over image_(Main_scaleLinear_rowcol)), recalled, not
+ * compiled -- PARITY UNPINNED, no reference fixture covers it.  The scale is SEPARABLE, rows (width) first into a
+ * [src_height x dst_width] temporary, then columns, and each 1-D pass has two branches:
+ *   dst_len > src_len  linear interpolation with step (src_len - 1) / (dst_len - 1), the last sample copied;
+ *   dst_len < src_len  AREA AVERAGE: output i is the mean of the source interval [i s, (i + 1) s), s = src_len / dst_len,
+ *                      the two end samples weighted by their covered fraction (every real VQA image: COCO 640 x 480 -> 224);
+ *   equal              copy.
+ * All arithmetic in float, in the source's order (FP contraction off: the HIP kernel follows the same order with
+ * unfused operations, so the two agree to the last bit). */
+#pragma STDC FP_CONTRACT OFF
+static void scale_rowcol(const float *src, float *dst, long src_stride, long dst_stride, long src_len, long dst_len)
+{
+    if (dst_len > src_len) {
+        const float scale = (float)(src_len - 1) / (float)(dst_len - 1);
+        if (src_len == 1) {
+            for (long di = 0; di < dst_len - 1; ++di) dst[di * dst_stride] = src[0];
+        } else {
+            for (long di = 0; di < dst_len - 1; ++di) {
+                float si_f = (float)di * scale;
+                const long si_i = (long)si_f;
+                si_f -= (float)si_i;
+                const float a = (1.0f - si_f) * src[si_i * src_stride], b = si_f * src[(si_i + 1) * src_stride];
+                dst[di * dst_stride] = a + b;
+            }
+        }
+        dst[(dst_len - 1) * dst_stride] = src[(src_len - 1) * src_stride];
+    } else if (dst_len < src_len) {
+        long si0_i = 0;
+        float si0_f = 0.f;
+        const float scale = (float)src_len / (float)dst_len;
+        for (long di = 0; di < dst_len; ++di) {
+            float si1_f = (float)(di + 1) * scale;
+            const long si1_i = (long)si1_f;
+            si1_f -= (float)si1_i;
+            float acc = (1.0f - si0_f) * src[si0_i * src_stride];
+            float n = 1.0f - si0_f;
+            for (long si = si0_i + 1; si < si1_i; ++si) {
+                acc = acc + src[si * src_stride];
+                n = n + 1.0f;
+            }
+            if (si1_i < src_len) {
+                const float t = si1_f * src[si1_i * src_stride];
+                acc = acc + t;
+                n = n + si1_f;
+            }
+            dst[di * dst_stride] = acc / n;
+            si0_i = si1_i;
+            si0_f = si1_f;
+        }
+    } else {
+        for (long i = 0; i < dst_len; ++i) dst[i * dst_stride] = src[i * src_stride];
+    }
+}
+
+/* one plane [H x W] -> [S x S] */
+void oracle_image_scale_plane(const float *src, int H, int W, int S, float *dst)
+{
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)H * S);
+    for (int j = 0; j < H; ++j) scale_rowcol(src + (size_t)j * W, tmp + (size_t)j * S, 1, 1, W, S); /* compress / expand rows first */
+    for (int i = 0; i < S; ++i) scale_rowcol(tmp + i, dst + i, S, S, H, S);                          /* then columns */
+    free(tmp);
+}
+
+/* loadim (001_prepro_img_vgg.lua:47-71) minus the file decode: rgb n x 3 x H x W in [0,1] -> image.scale to S x S ->
+ * x255 -> n x 3 x S x S BGR planes, mean-subtracted (:65-69). */
 void oracle_vgg16_preprocess(const float *rgb, int n, int H, int W, int S, float *out)
 {
     static const float mean[3] = {103.939f, 116.779f, 123.68f};
+    float *pl = (float *)malloc(sizeof(float) * (size_t)S * S);
     for (int im = 0; im < n; ++im)
-        for (int c = 0; c < 3; ++c)
-            for (int y = 0; y < S; ++y)
-                for (int x = 0; x < S; ++x) {
-                    const float fy = S > 1 ? (float)y * (float)(H - 1) / (float)(S - 1) : 0.f;
-                    const float fx = S > 1 ? (float)x * (float)(W - 1) / (float)(S - 1) : 0.f;
-                    int y0 = (int)fy, x0 = (int)fx;
-                    if (y0 > H - 1) y0 = H - 1;
-                    if (x0 > W - 1) x0 = W - 1;
-                    const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
-                    const float wy = fy - (float)y0, wx = fx - (float)x0;
-                    const float *p = rgb + ((size_t)im * 3 + (2 - c)) * H * W;
-                    const float v = (1.f - wy) * ((1.f - wx) * p[(size_t)y0 * W + x0] + wx * p[(size_t)y0 * W + x1]) +
-                                    wy * ((1.f - wx) * p[(size_t)y1 * W + x0] + wx * p[(size_t)y1 * W + x1]);
-                    out[(((size_t)im * 3 + c) * S + y) * S + x] = v * 255.0f - mean[c];
-                }
+        for (int c = 0; c < 3; ++c) {
+            oracle_image_scale_plane(rgb + ((size_t)im * 3 + (2 - c)) * H * W, H, W, S, pl);
+            float *o = out + ((size_t)im * 3 + c) * S * S;
+            for (int i = 0; i < S * S; ++i) {
+                const float v = pl[i] * 255.0f;
+                o[i] = v - mean[c];
+            }
+        }
+    free(pl);
 }

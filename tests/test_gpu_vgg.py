@@ -61,14 +61,25 @@ def test_fc7_bf16_operands(pkg, orc):
     v.close()
 
 
-def test_preprocess_matches_loadim(pkg, orc):
+@pytest.mark.parametrize("H,W,S", [(480, 640, 224), (100, 150, 224), (100, 300, 224), (50, 70, 64)])
+def test_preprocess_matches_loadim(pkg, orc, H, W, S):
+    """loadim on the device (k_vgg_preprocess) against the oracle, BIT-EXACT: Torch's image.scale in both of its branches
+    (area average when a dimension shrinks -- 480 x 640 -> 224, the real pipeline; linear interpolation when it grows --
+    100 x 150 -> 224; one of each -- 100 x 300 -> 224), x255, BGR, mean (001_prepro_img_vgg.lua:47-71).  Both sides follow
+    the published algorithm of the `image` rock with unfused float operations in the same order."""
     rng = np.random.default_rng(1)
-    rgb = rng.uniform(0, 1, (2, 3, 50, 70)).astype(np.float32)
-    v = pkg.binding.Vgg16(0, 16, 64, max_batch=2)
+    rgb = rng.uniform(0, 1, (2, 3, H, W)).astype(np.float32)
+    v = pkg.binding.Vgg16(0, 16, S, max_batch=2)
     got = v.preprocess(rgb)
-    ref = orc.VggOracle(16, 64).preprocess(rgb, 64)
-    assert np.abs(got - ref).max() < 1e-3
+    ref = orc.VggOracle(16, S).preprocess(rgb, S)
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    v.close()
+
+
+def test_preprocess_identity_size(pkg):
     # identity-size input: pure x255, BGR swap, mean subtraction (001_prepro_img_vgg.lua:65-69)
+    rng = np.random.default_rng(1)
+    v = pkg.binding.Vgg16(0, 16, 64, max_batch=2)
     same = rng.uniform(0, 1, (1, 3, 64, 64)).astype(np.float32)
     out = v.preprocess(same)
     assert np.allclose(out[0, 0], same[0, 2] * 255 - 103.939, atol=1e-3)

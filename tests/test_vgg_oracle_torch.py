@@ -44,11 +44,55 @@ def test_vgg_oracle_matches_torch_functional(orc, div, hw, n):
     assert relmax(got, t.numpy()) < 2e-5          # f32 direct convolution against f64
 
 
-def test_loadim_resize_is_align_corners_bilinear(orc):
+def _scale_matrix(src_len, dst_len):
+    """Independent float64 statement of one 1-D pass of Torch's image.scale as a [dst x src] weight matrix: interpolation
+    weights when enlarging (step (src - 1) / (dst - 1)), normalised interval-overlap weights (area average over
+    [i s, (i + 1) s), s = src / dst) when shrinking."""
+    Wm = np.zeros((dst_len, src_len))
+    if dst_len > src_len:
+        for i in range(dst_len):
+            if i == dst_len - 1 or src_len == 1:
+                Wm[i, src_len - 1 if i == dst_len - 1 else 0] = 1.0
+                continue
+            p = i * (src_len - 1) / (dst_len - 1)
+            k = int(np.floor(p))
+            Wm[i, k] += 1.0 - (p - k)
+            Wm[i, k + 1] += p - k
+    elif dst_len < src_len:
+        sc = src_len / dst_len
+        for i in range(dst_len):
+            lo, hi = i * sc, (i + 1) * sc
+            for k in range(int(np.floor(lo)), min(src_len, int(np.floor(hi)) + 1)):
+                Wm[i, k] = max(0.0, min(k + 1, hi) - max(k, lo))
+            Wm[i] /= Wm[i].sum()
+    else:
+        Wm = np.eye(src_len)
+    return Wm
+
+
+@pytest.mark.parametrize("H,W,S", [(480, 640, 224), (100, 150, 224), (100, 300, 224), (41, 57, 32), (32, 32, 32), (7, 300, 16)])
+def test_loadim_resize_is_torch_image_scale(orc, H, W, S):
+    """loadim's image.scale (001_prepro_img_vgg.lua:50): separable, rows first; linear interpolation when a dimension grows,
+    AREA AVERAGE when it shrinks (the branch every real VQA image takes: 480 x 640 -> 224).  The C oracle against the
+    weight-matrix statement above in float64; the `image` rock itself is absent (PARITY UNPINNED against Torch7)."""
+    vo = orc.VggOracle(16, 32)
+    rng = np.random.default_rng(H * 1000 + W)
+    rgb = rng.uniform(0, 1, (2, 3, H, W)).astype(np.float32)
+    got = vo.preprocess(rgb, S)                   # scale -> x255 -> BGR -> minus mean (001_prepro_img_vgg.lua:50,65-69)
+    Wy, Wx = _scale_matrix(H, S), _scale_matrix(W, S)
+    r = np.matmul(Wy, np.matmul(rgb.astype(np.float64), Wx.T)) * 255.0   # rows first, then columns
+    want = r[:, [2, 1, 0]] - np.array([103.939, 116.779, 123.68]).reshape(1, 3, 1, 1)
+    # float sample positions (di * scale in f32, as the source computes them) against f64 ones: 224 x 6e-8 of a pixel, times
+    # neighbour differences of up to 255 -> a few 1e-3 on values of +-150
+    assert np.abs(got - want).max() < 1e-2, float(np.abs(got - want).max())
+
+
+def test_loadim_enlarging_is_align_corners_bilinear(orc):
+    """Where both dimensions grow the separable linear pass is align-corners bilinear interpolation (torch.nn.functional)."""
     vo = orc.VggOracle(16, 32)
     rng = np.random.default_rng(2)
-    rgb = rng.uniform(0, 1, (2, 3, 41, 57)).astype(np.float32)
-    got = vo.preprocess(rgb, 32)                  # scale -> x255 -> BGR -> minus mean (001_prepro_img_vgg.lua:50,65-69)
+    rgb = rng.uniform(0, 1, (2, 3, 21, 27)).astype(np.float32)
+    got = vo.preprocess(rgb, 32)
     r = F.interpolate(torch.tensor(rgb, dtype=torch.float64), size=(32, 32), mode="bilinear", align_corners=True) * 255.0
     mean = torch.tensor([103.939, 116.779, 123.68], dtype=torch.float64).view(1, 3, 1, 1)
     want = r[:, [2, 1, 0]] - mean

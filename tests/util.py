@@ -28,14 +28,17 @@ def segment_errors(orc, d, got, ref, fusion=0):
     return out
 
 
-# ---- round-2 tolerances ---------------------------------------------------------------------------------------
+# ---- logit tolerance -----------------------------------------------------------------------------------------------
 # north_star: "within 1e-4 relative on fp32 logits, bit-exact for argmax indices".  Logits are compared ELEMENT by
-# element: |a - b| <= 1e-4 |b| + 1e-5 max_row|b|.  The second term covers logits that pass through zero: a logit is a
-# sum of C products whose f32 rounding noise is eps x the magnitude of the TERMS (the same for every logit of a
-# row), not of the sum, so an element is held to 1e-4 of itself down to a tenth of its row's largest logit and to
-# 1e-5 of that largest logit below.
+# element: |a - b| <= 1e-4 |b| + RTOL_LOGIT_ROW max_row|b|.  The second term covers logits that pass through zero: a
+# logit is a sum of C products whose f32 rounding noise is eps x the magnitude of the TERMS (the same for every logit
+# of a row), not of the sum.  Round 3 set it from a sweep over every parity case (gpurun_out/parity_r03.jsonl,
+# "logits_sweep": the error of each case against the row coefficients 1e-5 / 3e-6 / 2e-6 / 0): every case but one needs
+# <= 1.0e-6 (headline workload: 0.97e-6); the bias-saturated full-size arch1 case (logits up to +-214, sums of 1024
+# products of O(10) terms) measures 4.5e-6.  6e-6 holds that worst case at 0.75 x and everything else at <= 0.17 x
+# (round 2 used 1e-5; VERDICT r2 suggested <= 3e-6, which the measured worst case exceeds by 1.5 x).
 RTOL_LOGIT = 1e-4
-RTOL_LOGIT_ROW = 1e-5
+RTOL_LOGIT_ROW = 6e-6
 
 
 def _logit_tol(b):
@@ -52,9 +55,9 @@ def logits_err(got, ref, row=None):
 
 def assert_logits(got, ref, scale=1.0):
     e = logits_err(got, ref)
-    record("logits_sweep", {"x_tol": e, "x_tol_row3e-6": logits_err(got, ref, 3e-6), "x_tol_row2e-6": logits_err(got, ref, 2e-6),
-                            "x_tol_row0": logits_err(got, ref, 1e-30), "max_abs": float(np.abs(np.asarray(ref)).max())})
-    assert e <= scale, f"logits: worst element at {e:.3g} x tolerance (|a-b| <= 1e-4 |b| + 1e-5 max_row|b|), allowed {scale:.3g}"
+    record("logits_sweep", {"x_tol": e, "x_tol_row1e-5": logits_err(got, ref, 1e-5), "x_tol_row3e-6": logits_err(got, ref, 3e-6),
+                            "x_tol_row2e-6": logits_err(got, ref, 2e-6), "max_abs": float(np.abs(np.asarray(ref)).max())})
+    assert e <= scale, f"logits: worst element at {e:.3g} x tolerance (|a-b| <= 1e-4 |b| + 6e-6 max_row|b|), allowed {scale:.3g}"
     return e
 
 
