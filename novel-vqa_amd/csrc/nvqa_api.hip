@@ -340,6 +340,7 @@ static int create_impl(nvqa_ctx *c)
             NVQA_TRY(dalloc(&c->pb_bias, L * rbmax * 4 * R));
             if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
         }
+        { const char *es = getenv("NVQA_PF_SPIN"); c->pf_spin = es ? (unsigned)strtoul(es, nullptr, 0) : 0u; } // 0: the kernels' default
         NVQA_TRY(dalloc(&c->pf_sticky, 8));
         NVQA_HIP(hipMemsetAsync(c->pf_sticky, 0, 32, c->s));
         NVQA_TRY(dalloc(&c->dp_status, 4));
@@ -419,22 +420,23 @@ static int check_persist(nvqa_ctx *c)
                 }
         }
     }
-    if (c->h_pf_err && c->h_pf_err[4]) {
-        set_error("persistent BPTT kernel: workgroup %u timed out waiting (code 0x%x, value seen %u); results of that step are invalid",
-                  c->h_pf_err[7], c->h_pf_err[4], c->h_pf_err[6]);
-        memset(c->h_pf_err + 4, 0, 16);
-        (void)hipMemsetAsync(c->pf_sticky + 4, 0, 16, c->s); // reported: k_rmsprop may apply gradients again
-        c->persist_bwd_on = 0; // later steps take the per-level path
-        return -3;
-    }
-    if (c->h_pf_err && *c->h_pf_err) {
-        // word index relative to the err word: counters end 4 words before it
-        const long widx = (long)(int)c->h_pf_err[1] + (long)c->pf_cnt_words - 4;
-        set_error("persistent LSTM kernel: workgroup %u timed out waiting (code 0x%x, counter word %ld = (layer,rowblock) %ld step %ld, value seen %u); "
-                  "results of that step are invalid", c->h_pf_err[3], c->h_pf_err[0], widx, widx / c->TS, widx % c->TS, c->h_pf_err[2]);
-        *c->h_pf_err = 0;
-        (void)hipMemsetAsync(c->pf_sticky, 0, 16, c->s);
-        c->persist_on = false; // later steps take the per-level path
+    if (c->h_pf_err && (c->h_pf_err[0] || c->h_pf_err[4])) {
+        // one report for both kernels: a forward time-out leaves garbage that the BPTT kernel may also trip over
+        char fwd[256] = "", bwd[200] = "";
+        if (c->h_pf_err[0]) {
+            // word index relative to the err word: counters end 4 words before it
+            const long widx = (long)(int)c->h_pf_err[1] + (long)c->pf_cnt_words - 4;
+            snprintf(fwd, sizeof(fwd), "persistent LSTM kernel: workgroup %u timed out waiting (code 0x%x, counter word %ld = (layer,rowblock) %ld step %ld, value seen %u)",
+                     c->h_pf_err[3], c->h_pf_err[0], widx, widx / c->TS, widx % c->TS, c->h_pf_err[2]);
+            c->persist_on = false; // later steps take the per-level path
+        }
+        if (c->h_pf_err[4]) {
+            snprintf(bwd, sizeof(bwd), "persistent BPTT kernel: workgroup %u timed out waiting (code 0x%x, value seen %u)", c->h_pf_err[7], c->h_pf_err[4], c->h_pf_err[6]);
+            c->persist_bwd_on = 0;
+        }
+        set_error("%s%s%s; results of that step are invalid and were not applied", fwd, fwd[0] && bwd[0] ? "; " : "", bwd);
+        memset(c->h_pf_err, 0, 32);
+        (void)hipMemsetAsync(c->pf_sticky, 0, 32, c->s); // reported: k_rmsprop may apply gradients again
         return -3;
     }
     if (c->comm && c->h_dp_status && c->h_dp_status[0] != 0.f) {

@@ -132,6 +132,7 @@ struct nvqa_ctx {
     unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd.h)
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the sticky err records (forward: words 0-3, BPTT: words 4-7)
+    unsigned pf_spin = 0;         // NVQA_PF_SPIN at nvqa_create: polls before a persistent-kernel wait gives up (0: NVQA_PF_SPIN_LIMIT)
     unsigned *pf_sticky = nullptr; // device: first failure of a persistent kernel since the host last looked (persist_fwd.hip: k_err_latch)
     float *dp_status = nullptr, *h_dp_status = nullptr; // data parallel: [0] = ranks whose persistent kernel gave up in this step (summed by the exchange)
     int persist_bwd_on = -1;       // BPTT as one persistent launch (lstm_persist_bwd.h)

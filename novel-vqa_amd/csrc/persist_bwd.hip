@@ -87,7 +87,7 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         const size_t gs = (size_t)TS * B * 4 * R;
         if (!c->dg_b16) NVQA_HIP(hipMalloc((void **)&c->dg_b16, (size_t)L * gs * 2));
     }
-    static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }();
+    const unsigned lim = c->pf_spin ? c->pf_spin : NVQA_PF_SPIN_LIMIT;
     static const int dbg = [] { const char *e = getenv("NVQA_PB_DBG"); return e ? atoi(e) : 0; }();
     const int halves = ver == 2 ? 2 : 1;
     const size_t n_rec = (size_t)L * RB * halves * TS, n_up = (size_t)L * RB * halves * NU * TS;

@@ -107,7 +107,7 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     a.h0_top = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0) ? 1 : 0;
     a.dr = dr;
     { static const int dbg = [] { const char *e = getenv("NVQA_PF_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
-    { static const unsigned lim = [] { const char *e = getenv("NVQA_PF_SPIN"); return e ? (unsigned)strtoul(e, nullptr, 0) : NVQA_PF_SPIN_LIMIT; }(); a.spin_limit = lim; }
+    a.spin_limit = c->pf_spin ? c->pf_spin : NVQA_PF_SPIN_LIMIT;
     a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
     a.ts = c->pf_ts;
     const int grid = L * a.RB * a.NU;

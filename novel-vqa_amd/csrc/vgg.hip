@@ -92,30 +92,38 @@ __global__ void k_fc_finish(const float *slabs, int S, int M, int N, const float
 //   dst_len < src_len: area average over [di s, (di + 1) s), s = src_len / dst_len, end samples weighted by coverage;
 //   equal: copy.
 // `at(i)` returns source sample i.  Unfused float operations in the source's order (__f*_rn are never contracted).
+// a product that must be ROUNDED before it is added (the source's float arithmetic is unfused): the empty asm hides it from
+// the contraction of a * b + c into an fma, which neither __fmul_rn nor `#pragma clang fp contract(off)` prevented in this
+// HIP version (measured: identity-size inputs came back 1 ulp off in half the pixels)
+__device__ __forceinline__ float rounded(float x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
 template <class F> __device__ __forceinline__ float scale1d(F at, int src_len, int dst_len, int di)
 {
     if (dst_len > src_len) {
         if (di == dst_len - 1) return at(src_len - 1);
         if (src_len == 1) return at(0);
         const float scale = __fdiv_rn((float)(src_len - 1), (float)(dst_len - 1));
-        float si_f = __fmul_rn((float)di, scale);
+        float si_f = rounded(__fmul_rn((float)di, scale)); // (its integer part is subtracted next: no fma)
         const int si_i = (int)si_f;
         si_f = __fsub_rn(si_f, (float)si_i);
-        return __fadd_rn(__fmul_rn(__fsub_rn(1.0f, si_f), at(si_i)), __fmul_rn(si_f, at(si_i + 1)));
+        return __fadd_rn(rounded(__fmul_rn(__fsub_rn(1.0f, si_f), at(si_i))), rounded(__fmul_rn(si_f, at(si_i + 1))));
     }
     if (dst_len < src_len) {
         const float scale = __fdiv_rn((float)src_len, (float)dst_len);
-        float si0_f = __fmul_rn((float)di, scale), si1_f = __fmul_rn((float)(di + 1), scale);
+        float si0_f = rounded(__fmul_rn((float)di, scale)), si1_f = rounded(__fmul_rn((float)(di + 1), scale));
         const int si0_i = (int)si0_f, si1_i = (int)si1_f;
         si0_f = __fsub_rn(si0_f, (float)si0_i);
         si1_f = __fsub_rn(si1_f, (float)si1_i);
-        float acc = __fmul_rn(__fsub_rn(1.0f, si0_f), at(si0_i)), n = __fsub_rn(1.0f, si0_f);
+        float acc = rounded(__fmul_rn(__fsub_rn(1.0f, si0_f), at(si0_i))), n = __fsub_rn(1.0f, si0_f);
         for (int si = si0_i + 1; si < si1_i; ++si) {
             acc = __fadd_rn(acc, at(si));
             n = __fadd_rn(n, 1.0f);
         }
         if (si1_i < src_len) {
-            acc = __fadd_rn(acc, __fmul_rn(si1_f, at(si1_i)));
+            acc = __fadd_rn(acc, rounded(__fmul_rn(si1_f, at(si1_i))));
             n = __fadd_rn(n, si1_f);
         }
         return __fdiv_rn(acc, n);
@@ -141,7 +149,7 @@ __global__ void k_vgg_preprocess(const float *in, int n, int H, int W, int S, fl
         return scale1d([&](int k) { return row[k]; }, W, S, x);
     };
     const float v = scale1d(hrow, H, S, y);
-    out[i] = __fsub_rn(__fmul_rn(v, 255.0f), mean);
+    out[i] = __fsub_rn(rounded(__fmul_rn(v, 255.0f)), mean);
 }
 
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgConv;   // C_out >= 128: 8 waves of 32 x 64, 16x16x4 MFMA (tools/kbench3: 117 vs 95 TF for the K-contiguous x K-contiguous form)

@@ -312,3 +312,30 @@ def test_fused_bptt_level_opt_in(pkg, orc, kw):
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
     ref = orc.Oracle(np.float64).step(d, params, tok, lens, img, lab, orc.Dropout(1, 0.5, 123, 5))
     assert_grads(orc, d, out[0][1], ref["grads"], TOL_GRAD, "fused_bptt_level")
+
+
+def test_persistent_kernel_timeout_is_reported_and_survived(pkg, orc, monkeypatch):
+    """The give-up path of the persistent kernels: with NVQA_PF_SPIN = 1 every cross-workgroup wait gives up at
+    its second poll, so a full-size step MUST time out.  Required: the launch drains (no hang), the failure survives an
+    asynchronous trainer loop -- nvqa_step(loss_out = NULL) + nvqa_rmsprop_update before any synchronisation: the sticky
+    record makes k_rmsprop skip the update, the parameters stay bit-identical -- nvqa_sync returns an error that names the
+    counter, and the following steps (per-level kernels: the persistent paths switch themselves off) match the oracle."""
+    d = orc.make_dims(**FULL1)
+    params = orc.synth_params(d)
+    monkeypatch.setenv("NVQA_PF_SPIN", "1")
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)   # the limit is read at nvqa_create
+    monkeypatch.delenv("NVQA_PF_SPIN")
+    ctx.set_params(params)
+    p0 = ctx.get_params()
+    tok, lens, img, lab = orc.synth_batch(d, seed=123, full_length=True)
+    ctx.step(tok, lens, img, lab, gdrop(pkg, orc.Dropout(1, 0.5, 123, 1)), want_loss=False)
+    ctx.rmsprop_update(3e-4, 0.99, 1e-8, 0.0, 10.0)   # enqueued behind the failed step, before the host knows
+    with pytest.raises(pkg.binding.NvqaError) as e:
+        ctx.sync()
+    msg = str(e.value)
+    assert "timed out" in msg and "counter word" in msg and "not applied" in msg, msg
+    assert np.array_equal(ctx.get_params(), p0), "the update of a failed step was applied"
+    # the context lives on: the next steps run the per-level kernels and are right
+    b = orc.synth_batch(d, seed=77, full_length=True)
+    _check_step(pkg, orc, d, ctx, params, b, orc.Dropout(1, 0.5, 123, 2), TOL_GRAD, "after_timeout")
+    ctx.close()

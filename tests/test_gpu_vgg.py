@@ -16,7 +16,8 @@ def _images(n, hw, seed=5):
     return rgb[:, ::-1] * 255.0 - mean  # loadim: BGR planes, mean-subtracted
 
 
-@pytest.mark.parametrize("div,hw,n", [(16, 32, 3), (16, 64, 2), (8, 96, 2), (1, 64, 2), (1, 224, 1)])
+# (1, 224, 4): the reference's network at full width and full resolution, four images
+@pytest.mark.parametrize("div,hw,n", [(16, 32, 3), (16, 64, 2), (8, 96, 2), (1, 64, 2), (1, 224, 1), (1, 224, 4)])
 def test_fc7_matches_oracle(pkg, orc, div, hw, n):
     o = orc.VggOracle(div, hw)
     w = o.synth_weights()
