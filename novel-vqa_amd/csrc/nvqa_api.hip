@@ -361,7 +361,20 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     (void)hipDeviceSynchronize();
     prof_collect(c);
     comm_destroy(c);
-    void *ptrs[] = {c->P, c->G, c->M2, c->tok, c->len, c->lab, c->img, c->qinds, c->sort_idx, c->sort_inv,
+    if (c->hset[0].tok) { // two device sets + pinned staging of the host-batch entries
+        for (int p = 0; p < 2; ++p) {
+            for (void *q : {(void *)c->bset[p].tok, (void *)c->bset[p].len, (void *)c->bset[p].lab, (void *)c->bset[p].img})
+                if (q) (void)hipFree(q);
+            for (void *q : {(void *)c->hset[p].tok, (void *)c->hset[p].len, (void *)c->hset[p].lab, (void *)c->hset[p].img})
+                if (q) (void)hipHostFree(q);
+            if (c->evCopied[p]) (void)hipEventDestroy(c->evCopied[p]);
+            if (c->evBatchFree[p]) (void)hipEventDestroy(c->evBatchFree[p]);
+        }
+    } else {
+        for (void *q : {(void *)c->tok, (void *)c->len, (void *)c->lab, (void *)c->img})
+            if (q) (void)hipFree(q);
+    }
+    void *ptrs[] = {c->P, c->G, c->M2, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
                     c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT, c->mc,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->bwd_cnt, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
@@ -1166,6 +1179,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
 // ------------------------------------------------------------------------------------
 // the step
 // ------------------------------------------------------------------------------------
+static int batch_release(nvqa_ctx *c); // with upload_batch, below
 static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
 {
     const Drop dr = mkdrop(dropout, true);
@@ -1177,6 +1191,7 @@ static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
         NVQA_TRY(arch2_forward(c, dr, true, false));
         NVQA_TRY(arch2_backward(c, dr));
     }
+    NVQA_TRY(batch_release(c)); // (arch2's backward pass reads the image features once more: dW_p)
     NVQA_TRY(reduce_join(c));
     c->have_grads = true;
     NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
@@ -1194,7 +1209,7 @@ static int upload_batch(nvqa_ctx *c, int n, const int32_t *tokens, const int32_t
     const nvqa_dims &d = c->d;
     const size_t B = d.B, T = d.T, I = d.I;
     if (n < 1 || n > d.B) { set_error("batch rows %d outside 1..%d", n, d.B); return -1; }
-    if (!tokens || !img || (d.arch == NVQA_ARCH1 && !lengths)) { set_error("NULL batch pointer"); return -1; }
+    if (!tokens || (d.arch == NVQA_ARCH1 && !lengths)) { set_error("NULL batch pointer"); return -1; }
     // validate on the host: a bad index would fault on the device
     std::vector<int32_t> tk(B * T), ln(B), lb(B, 1);
     std::vector<float> im;
@@ -1219,17 +1234,50 @@ static int upload_batch(nvqa_ctx *c, int n, const int32_t *tokens, const int32_t
     }
     c->batch_uniform = true;
     for (size_t b = 1; b < B; ++b) c->batch_uniform = c->batch_uniform && ln[b] == ln[0];
-    NVQA_HIP(hipStreamSynchronize(c->s));
-    NVQA_HIP(hipMemcpy(c->tok, tk.data(), B * T * 4, hipMemcpyHostToDevice));
-    NVQA_HIP(hipMemcpy(c->len, ln.data(), B * 4, hipMemcpyHostToDevice));
-    NVQA_HIP(hipMemcpy(c->lab, lb.data(), B * 4, hipMemcpyHostToDevice));
-    if ((size_t)n == B) {
-        NVQA_HIP(hipMemcpy(c->img, img, B * I * 4, hipMemcpyHostToDevice));
-    } else {
-        im.resize(B * I);
-        for (size_t b = 0; b < B; ++b) memcpy(&im[b * I], img + (b < (size_t)n ? b : 0) * I, I * 4);
-        NVQA_HIP(hipMemcpy(c->img, im.data(), B * I * 4, hipMemcpyHostToDevice));
+    // ---- pinned staging -> the device set the running step does not read, on the side stream --------------------------------
+    if (!c->hset[0].tok) { // first host-batch call: the second device set, two pinned staging sets, the events
+        c->bset[0] = {c->tok, c->len, c->lab, c->img};
+        NVQA_TRY(dalloc(&c->bset[1].tok, B * T));
+        NVQA_TRY(dalloc(&c->bset[1].len, B));
+        NVQA_TRY(dalloc(&c->bset[1].lab, B));
+        NVQA_TRY(dalloc(&c->bset[1].img, B * I));
+        for (int p = 0; p < 2; ++p) {
+            NVQA_HIP(hipHostMalloc((void **)&c->hset[p].tok, B * T * 4, hipHostMallocDefault));
+            NVQA_HIP(hipHostMalloc((void **)&c->hset[p].len, B * 4, hipHostMallocDefault));
+            NVQA_HIP(hipHostMalloc((void **)&c->hset[p].lab, B * 4, hipHostMallocDefault));
+            NVQA_HIP(hipHostMalloc((void **)&c->hset[p].img, B * I * 4, hipHostMallocDefault));
+            NVQA_HIP(hipEventCreateWithFlags(&c->evCopied[p], hipEventDisableTiming));
+            NVQA_HIP(hipEventCreateWithFlags(&c->evBatchFree[p], hipEventDisableTiming));
+        }
     }
+    const int p = c->bcur ^ 1;
+    if (c->copied_rec[p]) NVQA_HIP(hipEventSynchronize(c->evCopied[p])); // the staging set's previous copy (two calls ago) is long done
+    memcpy(c->hset[p].tok, tk.data(), B * T * 4);
+    memcpy(c->hset[p].len, ln.data(), B * 4);
+    memcpy(c->hset[p].lab, lb.data(), B * 4);
+    if (img) {
+        if ((size_t)n == B) memcpy(c->hset[p].img, img, B * I * 4);
+        else for (size_t b = 0; b < B; ++b) memcpy(c->hset[p].img + b * I, img + (b < (size_t)n ? b : 0) * I, I * 4);
+    }
+    if (c->batch_free_rec[p]) NVQA_HIP(hipStreamWaitEvent(c->sx, c->evBatchFree[p], 0)); // the step that read device set p has run
+    NVQA_HIP(hipMemcpyAsync(c->bset[p].tok, c->hset[p].tok, B * T * 4, hipMemcpyHostToDevice, c->sx));
+    NVQA_HIP(hipMemcpyAsync(c->bset[p].len, c->hset[p].len, B * 4, hipMemcpyHostToDevice, c->sx));
+    NVQA_HIP(hipMemcpyAsync(c->bset[p].lab, c->hset[p].lab, B * 4, hipMemcpyHostToDevice, c->sx));
+    if (img) NVQA_HIP(hipMemcpyAsync(c->bset[p].img, c->hset[p].img, B * I * 4, hipMemcpyHostToDevice, c->sx));
+    NVQA_HIP(hipEventRecord(c->evCopied[p], c->sx));
+    c->copied_rec[p] = true;
+    NVQA_HIP(hipStreamWaitEvent(c->s, c->evCopied[p], 0));
+    c->bcur = p;
+    c->tok = c->bset[p].tok; c->len = c->bset[p].len; c->lab = c->bset[p].lab; c->img = c->bset[p].img;
+    return 0;
+}
+
+// behind the last kernel of a step that reads the batch buffers: device set bcur may be refilled
+static int batch_release(nvqa_ctx *c)
+{
+    if (!c->hset[0].tok) return 0;
+    NVQA_HIP(hipEventRecord(c->evBatchFree[c->bcur], c->s));
+    c->batch_free_rec[c->bcur] = true;
     return 0;
 }
 
@@ -1237,7 +1285,7 @@ extern "C" int nvqa_step(nvqa_ctx *c, const int32_t *tokens, const int32_t *leng
                          const int32_t *labels, const nvqa_dropout *dropout, float *loss_out)
 {
     if (!c) { set_error("ctx is NULL"); return -1; }
-    if (!labels) { set_error("labels is NULL"); return -1; }
+    if (!labels || !img) { set_error("labels / img is NULL"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     NVQA_TRY(upload_batch(c, c->d.B, tokens, lengths, img, labels));
     return run_step(c, dropout, loss_out);
@@ -1255,9 +1303,8 @@ extern "C" int nvqa_step_images(nvqa_ctx *c, nvqa_vgg *vgg, const float *images,
 {
     if (!c || !vgg || !images || !labels) { set_error("NULL argument"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
-    // tokens / lengths / labels go through the usual validated upload; the image slot gets a dummy
-    std::vector<float> zero((size_t)c->d.B * c->d.I, 0.f);
-    NVQA_TRY(upload_batch(c, c->d.B, tokens, lengths, zero.data(), labels));
+    // tokens / lengths / labels go through the usual validated upload; the image slot is filled below
+    NVQA_TRY(upload_batch(c, c->d.B, tokens, lengths, nullptr, labels));
     const float *feats = nullptr;
     int F = 0;
     hipStream_t vs = nullptr;

@@ -94,7 +94,14 @@ struct nvqa_ctx {
     bool pristine = true;             // no parameters set yet: the layout may still change (nvqa_set_fusion)
     float gscale[3] = {1.f, 1.f, 1.f}; // per-segment gradient scale before the clamp (-lr_scale)
 
-    // current batch
+    // current batch.  tok / len / lab / img point at one of two device sets: the host-batch entries (nvqa_step, nvqa_forward,
+    // nvqa_evaluate) stage the caller's arrays in pinned memory and copy them on the side stream into the set the running
+    // step does NOT read, so the JdJ-shaped entry neither synchronises nor serialises its copies with the compute stream
+    struct BatchSet { int32_t *tok = nullptr, *len = nullptr, *lab = nullptr; float *img = nullptr; };
+    BatchSet bset[2], hset[2];        // device sets / pinned host staging (set 1 and the staging: first host-batch call)
+    int bcur = 0;                     // the set tok / len / lab / img point at
+    hipEvent_t evCopied[2] = {}, evBatchFree[2] = {}; // H2D of set p complete / the last step that read set p has run
+    bool batch_free_rec[2] = {false, false}, copied_rec[2] = {false, false};
     int32_t *tok = nullptr, *len = nullptr, *lab = nullptr;
     float *img = nullptr;
     int64_t *qinds = nullptr;
