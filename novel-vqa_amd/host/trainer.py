@@ -146,6 +146,63 @@ class VQATrainer:
     def load_checkpoint(self, path, encoder_perm=None):
         self.set_params(t7.load_checkpoint(path, self.dims.arch, self.ctx.segments(), encoder_perm=encoder_perm))
 
+    # -- initialisation from an auto-encoder checkpoint (the *_ae_based* scripts) -------------------------------------------
+    def init_from_autoencoder(self, path, encoder_perm=None, with_multimodal=False):
+        """What the AE-based trainers do in place of `*_w:uniform(-0.08, 0.08)`.
+
+        arch1 (002_train_vqa_arch1/003_train_ae_based.lua:65,175-186; _inc / _ef alike): `path` is the table written by
+        001_train_autoencoder/002_convert_text_model_arch1.lua:27-39 -- lookup = the AE's LookupTable weight transposed,
+        [E x (V+1)], encoder = the AE encoder's flat parameters.  embedding weight <- lookup[:, 1 .. V] (the last column,
+        the START token of the AE, is dropped), embedding bias <- 0, encoder_w_q <- encoder, multimodal_w <-
+        uniform(-0.08, 0.08).  with_multimodal (003_train_ae_based_wp.lua:153-160): the fusion projections W_q, b_q, W_v,
+        b_v are copied from the table's 'multimodal' tensor as well and only the classifier Linear(C, A) is uniform.
+
+        arch2 (003_train_vqa_arch2/003_train_ae_based.lua:74-75,150-152,186-194) clones modelT.ae.encoder and
+        modelT.ae.lookup_table out of the AE checkpoint's nn modules; this reader takes tensors only (nothing in a file
+        is executed), so `path` is the table lua/convert_ae_arch2.lua writes from that checkpoint: encoder = the LSTM's
+        flat parameters, lookup_table = [(V+1) x E].  cnn_w and multimodal_w <- uniform(-0.08, 0.08) (:189,194).
+
+        The uniform segments come from the library's counter-based stream (nvqa_init_params with this trainer's seed), so
+        every rank of a data-parallel job builds the same vector.  As with load_checkpoint, the order of the LSTM tensors
+        inside `encoder` is nngraph's: a table without layout = 'nvqa' needs encoder_perm (t7.encoder_permutation).
+        PARITY UNPINNED: the reference ships no AE checkpoint."""
+        d = self.dims
+        t = t7.load(path)
+        if t.get("layout") != t7.LAYOUT_MARK and encoder_perm is None:
+            raise ValueError("auto-encoder table has no layout = 'nvqa' marker: the order of the LSTM tensors inside 'encoder' is "
+                             "unknown (nngraph forward-node order); pass encoder_perm = t7.encoder_permutation(...)")
+        self.ctx.init_params(self.seed, -0.08, 0.08)
+        x = self.ctx.get_params()
+        seg = self.ctx.segments()
+        enc = np.asarray(t["encoder"], np.float32).ravel().copy()
+        if encoder_perm is not None:
+            enc[:len(encoder_perm)] = enc[np.asarray(encoder_perm)]
+        if d.arch == 1:
+            lookup = np.asarray(t["lookup"], np.float32)
+            if lookup.ndim != 2 or lookup.shape != (d.E, d.V + 1):
+                raise ValueError(f"lookup is {lookup.shape}, the model wants ({d.E}, {d.V + 1}) = [E x (V + 1)]")
+            if enc.size != seg[0]:
+                raise ValueError(f"encoder has {enc.size} values, the model wants {seg[0]}")
+            x[:seg[0]] = enc
+            x[seg[0]:seg[0] + d.E * d.V] = lookup[:, :d.V].ravel()          # Linear(V, E).weight [E x V]
+            x[seg[0] + d.E * d.V:seg[0] + seg[1]] = 0.0                      # Linear bias <- 0 (:178)
+            if with_multimodal:
+                mm = np.asarray(t["multimodal"], np.float32).ravel()
+                n_fuse = d.C * (2 * d.R * d.L) + d.C + d.C * d.I + d.C       # W_q, b_q, W_v, b_v
+                if mm.size != n_fuse:
+                    raise ValueError(f"multimodal has {mm.size} values, the fusion projections want {n_fuse}")
+                x[seg[0] + seg[1]:seg[0] + seg[1] + n_fuse] = mm
+        else:
+            lk = np.asarray(t["lookup_table"], np.float32)
+            if lk.shape != (d.V + 1, d.E):
+                raise ValueError(f"lookup_table is {lk.shape}, the model wants ({d.V + 1}, {d.E})")
+            n_lstm = seg[1] - lk.size
+            if enc.size != n_lstm:
+                raise ValueError(f"encoder has {enc.size} values, the model's LSTM wants {n_lstm}")
+            x[seg[0]:seg[0] + n_lstm] = enc
+            x[seg[0] + n_lstm:seg[0] + seg[1]] = lk.ravel()
+        self.ctx.set_params(x)
+
     def close(self):
         self.ctx.close()
 

@@ -117,3 +117,57 @@ def test_lua_cdef_prototypes_equal_the_header():
         return fields
     for st in ("nvqa_dims", "nvqa_dropout"):
         assert struct_fields(hdr, st) == struct_fields(cdef, st), st
+
+
+def _lua_code(path):
+    """Lua source with comments and string literals blanked (enough for the static checks below)."""
+    s = open(path).read()
+    s = re.sub(r"--\[\[.*?\]\]--?", " ", s, flags=re.S)       # block comments
+    s = re.sub(r"\[\[.*?\]\]", '""', s, flags=re.S)           # long strings (the cdef)
+    s = re.sub(r"--[^\n]*", " ", s)                           # line comments
+    s = re.sub(r"'(?:\\.|[^'\\\n])*'", "''", s)
+    s = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', s)
+    return s
+
+
+def _call_args(code, start):
+    """number of top-level arguments of the call whose '(' is at code[start]"""
+    depth, n, i, empty = 0, 1, start, True
+    while i < len(code):
+        c = code[i]
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+            if depth == 0:
+                return 0 if empty else n
+        elif depth == 1 and c == ",":
+            n += 1
+        elif depth >= 1 and not c.isspace():
+            empty = False
+        i += 1
+    raise AssertionError("unbalanced call")
+
+
+def test_lua_scripts_call_the_abi_with_the_declared_arity_and_balance_their_blocks():
+    """The Lua twins cannot be executed in the build image (no LuaJIT), so they are at least held to what can be checked
+    statically: every nvqa.lib.nvqa_* call names a function of include/nvqa.h and passes as many arguments as its prototype
+    takes, and every block opener (function / if / do / repeat) has its closer."""
+    hdr = open(os.path.join(ROOT, "include", "nvqa.h")).read()
+    protos = _prototypes(hdr)
+    arity = {n: (0 if p.endswith("()") else p.count(",") + 1) for n, p in protos.items()}
+    lua_dir = os.path.join(ROOT, "novel-vqa_amd", "lua")
+    files = sorted(f for f in os.listdir(lua_dir) if f.endswith(".lua"))
+    assert len(files) >= 9
+    for fn in files:
+        code = _lua_code(os.path.join(lua_dir, fn))
+        for m in re.finditer(r"nvqa\.lib\.(nvqa_[a-z0-9_]+)\s*\(", code):
+            name = m.group(1)
+            assert name in arity, f"{fn}: {name} is not declared in include/nvqa.h"
+            got = _call_args(code, m.end() - 1)
+            assert got == arity[name], f"{fn}: {name} called with {got} arguments, the header declares {arity[name]}"
+        opens = len(re.findall(r"\bfunction\b", code)) + len(re.findall(r"(?<![A-Za-z_])if\b", code)) + len(re.findall(r"\bdo\b", code))
+        opens -= len(re.findall(r"\belseif\b", code)) * 0     # 'elseif' is one token: the regex above does not match inside it
+        closes = len(re.findall(r"\bend\b", code))
+        assert opens == closes, f"{fn}: {opens} block openers, {closes} 'end'"
+        assert len(re.findall(r"\brepeat\b", code)) == len(re.findall(r"\buntil\b", code))

@@ -209,3 +209,32 @@ def test_embedding_gradient_skewed_vocabulary(pkg, orc, arch):
     a, b = got["1"][o:o + n], got["0"][o:o + n]
     assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
     assert np.count_nonzero(a) > 0
+
+
+def test_init_from_autoencoder_through_the_library(pkg, orc, tmp_path):
+    """VQATrainer.init_from_autoencoder (003_train_ae_based.lua:65,175-186) on a real context: the embedding weight crosses
+    the ABI in Torch's nn.Linear layout [E x V] (the device keeps it transposed), the uniform segments come from
+    nvqa_init_params, and a training step runs on the result."""
+    import numpy as np
+    d = orc.make_dims(arch=1, B=16, T=6, V=37, E=24, R=32, L=2, I=48, C=40, A=12)
+    tr = pkg.trainer.VQATrainer(pkg.binding.Dims(*[getattr(d, n) for n, _ in d._fields_]), device=0, seed=5)
+    seg = tr.ctx.segments()
+    rng = np.random.default_rng(0)
+    lookup = (0.1 * rng.standard_normal((d.E, d.V + 1))).astype(np.float32)
+    enc = (0.05 * rng.standard_normal(seg[0])).astype(np.float32)
+    path = str(tmp_path / "ae.t7")
+    pkg.t7.save(path, {"lookup": lookup, "encoder": enc, "layout": "nvqa"})
+    tr.init_params()
+    uniform = tr.get_params()
+    tr.init_from_autoencoder(path)
+    x = tr.get_params()
+    e, m = seg[0], seg[1]
+    assert np.array_equal(x[:e], enc)
+    assert np.array_equal(x[e:e + d.E * d.V].reshape(d.E, d.V), lookup[:, :d.V])
+    assert not x[e + d.E * d.V:e + m].any()
+    assert np.array_equal(x[e + m:], uniform[e + m:]) and np.abs(x[e + m:]).max() <= 0.08
+    tok, lens, img, lab = orc.synth_batch(d, full_length=False)
+    f, g = tr.JdJ((tok, lens, img, lab))
+    ref = orc.Oracle(np.float64).step(d, x, tok, lens, img, lab, orc.Dropout(1, 0.5, tr.dropout_seed, 0))
+    assert abs(f - ref["loss"]) <= 2e-6 * abs(ref["loss"])
+    tr.close()
