@@ -233,26 +233,9 @@ struct EpiLstmBwd {
     }
 };
 
-// epilogues with a preload() step (see EpiLstmFwd::Pre)
-// slab store of the fused BPTT level (lstm_bwd_level.h): tile-native element order, one 16-byte write-through store per
-// lane and MFMA tile (element-wise 4-byte sc1 stores made the level 1.8x slower)
-struct EpiSlabTile {
-    float *C;         // slab z at C + z * slab, tile t at + t * tile_elems
-    size_t slab;
-    unsigned tile_elems;
-    unsigned bytes;   // extent of all slabs (buffer resource)
-    __device__ __forceinline__ void operator()(int, int, int, float) const {} // (element form unused)
-    __device__ __forceinline__ void store4(int z, unsigned tile, unsigned slot, const float __attribute__((ext_vector_type(4))) & v) const
-    {
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (unsigned)(((size_t)z * slab + (size_t)tile * tile_elems + 4u * slot) * 4), 0, 16 /* sc1 */);
-    }
-};
-
+// epilogues with a preload() step (see EpiLstmFwd::Pre); vec4: a tile-native 16-byte store form (no epilogue uses it now)
 template <class E> struct EpiTraits { static constexpr bool prefetch = false; static constexpr bool vec4 = false; struct Pre {}; };
 template <> struct EpiTraits<EpiLstmFwd> { static constexpr bool prefetch = true; static constexpr bool vec4 = false; typedef EpiLstmFwd::Pre Pre; };
 template <> struct EpiTraits<EpiLstmBwd> { static constexpr bool prefetch = true; static constexpr bool vec4 = false; typedef EpiLstmBwd::Pre Pre; };
-template <> struct EpiTraits<EpiSlabTile> { static constexpr bool prefetch = false; static constexpr bool vec4 = true; struct Pre {}; };
 
 } // namespace nvqa

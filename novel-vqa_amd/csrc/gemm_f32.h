@@ -651,7 +651,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     }
     // tile-native epilogue (EpiTraits::vec4, MF = 16, WK = 1): the lane's 4 accumulator registers of an MFMA tile go out
     // as ONE 16-byte store into a slab whose element order is private to the producer and its consumer
-    // (lstm_bwd_level.h): slot = ((wave * NTM + ta) * NTN + tb) * 64 + lane
+    // (no epilogue uses it since round 3 removed the fused BPTT level kernel): slot = ((wave * NTM + ta) * NTN + tb) * 64 + lane
     if constexpr (EpiTraits<Epi>::vec4) {
         static_assert(MF == 16 && WK == 1 && !GATES && SEG == 0, "vec4 epilogue: 16x16 MFMA tiles, no K-group split");
         const unsigned tile = by * ((g.N + BN - 1) / BN) + bx;

@@ -850,19 +850,6 @@ __global__ void k_clamp_copy(const float *g, float *out, size_t n, float clamp, 
     }
 }
 
-// dst[c][r] = src[r][c] (src [rows][cols]); 32 x 32 tiles through LDS, both sides coalesced.  Used once per
-// step to give the BPTT level products a K-contiguous weight (W^T [in][4R]) for the LDS-DMA ring kernel.
-__global__ void k_transpose(const float *src, int rows, int cols, float *dst)
-{
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 256 threads: 8 rows per pass
-    for (int j = ty; j < 32; j += 8)
-        if (r0 + j < rows && c0 + tx < cols) t[j][tx] = src[(size_t)(r0 + j) * cols + c0 + tx];
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8)
-        if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * rows + r0 + tx] = t[tx][j];
-}
 
 __global__ void k_fill(float *p, size_t n, float v)
 {

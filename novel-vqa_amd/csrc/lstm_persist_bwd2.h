@@ -101,8 +101,10 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS, L = a.L, RBn = a.RB;
 
-    // workgroup -> (role, row block, unit tile): as lstm_persist_bwd.h (the NU unit tiles of one (role, row block) group on one
-    // XCD, REC(l+1, rb) next to the UP(l, rb) that reads its output; speed only)
+    // workgroup -> (role, row block, unit tile).  roles: 0 .. L-1 = REC(l = L-1-role), top layer first; L .. 2L-2 = UP(l = 2L-2-role).
+    // The NU unit tiles of one (role, row block) group exchange dG among themselves: they sit on ONE XCD (workgroups are dealt
+    // round-robin to the 8 XCDs: id % 8), REC(l+1, rb) next to the UP(l, rb) that reads its output.  Speed only: the protocol does
+    // not depend on the placement.  Grid = 8 XCDs x 32 slots; slots without a group leave at once.
     const int ngroups = (2 * L - 1) * RBn, gpx = 32 / a.NU > 0 ? 32 / a.NU : 1;
     const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int gslot = xcd * gpx + slot / a.NU, ut = slot % a.NU;
@@ -130,8 +132,15 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             if constexpr (!BF) {
                 bw[nt][g] = __builtin_bit_cast(pf_u32x4, pf_f32x4{w0[0], w0[(size_t)R], w0[2 * (size_t)R], w0[3 * (size_t)R]});
             } else {
+                pf_u32x4 q;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bw[nt][g][j] = pf_pack_bf16(w0[(size_t)(2 * j) * R], w0[(size_t)(2 * j + 1) * R]);
+                for (int j = 0; j < 4; ++j) q[j] = pf_pack_bf16(w0[(size_t)(2 * j) * R], w0[(size_t)(2 * j + 1) * R]);
+                // the fragment is born as ONE 128-bit value in an aligned AGPR quad and stays there (the MFMA's B operand, "a"
+                // constraint): assembled from four 32-bit values hipcc kept the pieces apart and copied them into a scratch
+                // AGPR quad in front of every MFMA -- and, not knowing that the asm statement is a matrix instruction, wrote
+                // that quad again while the previous MFMA was still reading it (all-NaN gradients)
+                asm volatile("" : "+a"(q));
+                bw[nt][g] = q;
             }
         }
     if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 1] = wall_clock64();
@@ -228,8 +237,20 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             }
         }
     };
-    auto pb_nop_after_clear = [] { asm volatile("s_nop 7" ::: "memory"); };
-    auto pb_nop_before_read = [] { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); };
+    // The wait states must sit BETWEEN the instructions they separate, and the compiler may move anything that does not
+    // depend on an asm statement across it.  So the accumulators pass THROUGH empty asm statements ("+v"): the v_movs that
+    // clear them are ordered in front of the first one, the nops follow, and the first MFMA consumes the asm's outputs;
+    // likewise the first read of an accumulator consumes the output of an asm that follows the nops behind the last MFMA.
+    // (Without this a ragged bf16 instance came out with its clears scheduled directly in front of the first MFMAs: LSTM
+    // gradients 10-30 % off while every other instance happened to pass.)
+    auto pb_touch_acc = [&] {
+#pragma unroll
+        for (int m = 0; m < GE::MTH; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) asm volatile("" : "+v"(acc[m][nt]));
+    };
+    auto pb_nop_after_clear = [&] { pb_touch_acc(); asm volatile("s_nop 7" ::: "memory"); };
+    auto pb_nop_before_read = [&] { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); pb_touch_acc(); };
 
     // epilogue ownership: thread -> (row rho = erow + RPP e of the half, units u0 + 4 eq .. +3)
     constexpr int QPR = GE::QPR, RPP = GE::RPP, NE = GE::NE;
@@ -439,7 +460,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
         const int act = act_of(H, s), actn = act_of(HN, sn);
         const int nr = a.nrows[s]; // (requested here: a load in the epilogue would wait for the prefetches in flight)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < GE::MTH; ++m)
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) acc[m][nt] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         pb_nop_after_clear();

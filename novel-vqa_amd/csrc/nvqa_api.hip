@@ -15,10 +15,8 @@
 #include <vector>
 
 #include "gemm_f32.h"
-#include "gemm_ring.h"
 #include "kernels.h"
 #include "wgrad_bf16.h"
-#include "lstm_bwd_level.h"
 #include "nvqa_ctx.h"
 #include "persist_host.h"
 
@@ -301,21 +299,10 @@ static int create_impl(nvqa_ctx *c)
     NVQA_TRY(dalloc(&c->colpart, 64 * widest));
     c->slab_floats = 8 * 4 * R * std::max<size_t>(std::max(R, E), 128);
     NVQA_TRY(dalloc(&c->slabs, c->slab_floats));
-    // (rows and units padded to whole 64 x 64 tiles: the fused level kernel stores tile-native slabs)
     NVQA_TRY(dalloc(&c->chain_slabs, (size_t)L * 2 * NVQA_BWD_ZMAX * ((B + 63) / 64 * 64) * ((R + 63) / 64 * 64)));
-    { // arrival counters of the fused BPTT levels (lstm_bwd_level.h): [diagonal][layer][output tile]
-        const char *e = getenv("NVQA_BWD_FUSE");
-        c->bwd_fuse = e && e[0] == '1'; // opt-in: measured slower than the two-launch form (lstm_bwd_level.h)
-        c->bwd_cnt_words = (size_t)(TS + L) * NVQA_MAX_LAYERS * ((R + 63) / 64) * ((B + 63) / 64);
-        NVQA_TRY(dalloc(&c->bwd_cnt, c->bwd_cnt_words));
-    }
-    {   // LDS-DMA ring level kernels (gemm_ring.h): opt-in with NVQA_RING=1.  Measured equal to the
-        // register-staged kernels within +-4 % (tools/kbench6, kbench9), so they are not the default.
+    {   // NVQA_FOLD_I2H=0: layer 0's input projection as a separate time-batched GEMM (A/B runs of the per-level path)
         const char *ef = getenv("NVQA_FOLD_I2H");
         c->fold_i2h = !(ef && ef[0] == '0');
-        const char *env = getenv("NVQA_RING");
-        c->use_ring = env && env[0] == '1' && R % 32 == 0 && (4 * R / NVQA_BWD_Z) % NVQA_RING_BK == 0;
-        if (c->use_ring) NVQA_TRY(dalloc(&c->WT, (size_t)L * 2 * 4 * R * R));
     }
     {   // persistent forward LSTM (lstm_persist.h) where the shape is eligible; NVQA_PERSIST=0: one launch per wavefront level
         const char *ep = getenv("NVQA_PERSIST");
@@ -376,8 +363,8 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     }
     void *ptrs[] = {c->P, c->G, c->M2, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
-                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->WT, c->mc,
-                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->bwd_cnt, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
+                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->mc,
+                    c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int l = 0; l < NVQA_MAX_LAYERS; ++l) {
@@ -725,10 +712,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
         ProfScope ps(c, PF_LSTM_FWD, flops, bytes);
         static const int fwd_map = [] { const char *e = getenv("NVQA_FWD_MAP"); return e ? atoi(e) : 0; }();
         ma.xcd = fwd_map;
-        bool ring = c->use_ring && !c->bf16;
-        for (int i = 0; i < np && ring; ++i) ring = ring_ok(ma.g[i], true);
-        if (ring) NVQA_HIP((launch_gemm_ring_multi<true, EpiLstmFwd, 1>(c->s, ma, np)));
-        else if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgLstmFwd>::type, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
+        if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgLstmFwd>::type, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
         else NVQA_HIP((launch_gemm_multi<CfgLstmFwd, A_KC, B_KC, true, EpiLstmFwd, 1>(c->s, ma, np)));
     }
     return 0;
@@ -747,29 +731,11 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         int RB = 0;
         if (const int MT = persist_bwd_rows(c, &RB)) { c->img_bwd_valid = c->bf16; return lstm_backward_persist(c, dr, MT, RB); }
     }
-    const bool ring = c->use_ring && !c->bf16;
-    const size_t wt = (size_t)4 * R * R;
-    if (ring) { // W_h2h^l [4R][R] -> [R][4R], W_i2h^l (l >= 1) likewise: the level products become K-contiguous x K-contiguous
-        ProfScope ps(c, PF_TRANSPOSE, 0, (double)(2 * L - 1) * wt * 8);
-        for (int l = 0; l < L; ++l) {
-            hipLaunchKernelGGL(k_transpose, dim3(R / 32, 4 * R / 32), dim3(256), 0, c->s, c->P + c->lo.w_h2h[l], 4 * R, R,
-                               c->WT + ((size_t)l * 2 + 0) * wt);
-            if (l > 0)
-                hipLaunchKernelGGL(k_transpose, dim3(R / 32, 4 * R / 32), dim3(256), 0, c->s, c->P + c->lo.w_i2h[l], 4 * R, R,
-                                   c->WT + ((size_t)l * 2 + 1) * wt);
-        }
-        NVQA_HIP(hipGetLastError());
-    }
-    // NVQA_BWD_FUSE=1: slab sums + cell backward inside the level kernel (lstm_bwd_level.h) instead of a second launch per
-    // level (k_lstm_bwd_finish); parity-green, slower, off by default
-    const int fuse_tiles = ((R + CfgBwdLevel::BN - 1) / CfgBwdLevel::BN) * ((B + CfgBwdLevel::BM - 1) / CfgBwdLevel::BM);
-    const bool fuse = c->bwd_fuse && !ring && c->bwd_cnt && (size_t)(TS + L) * NVQA_MAX_LAYERS * fuse_tiles <= c->bwd_cnt_words;
-    if (fuse) NVQA_HIP(hipMemsetAsync(c->bwd_cnt, 0, (size_t)(TS + L) * NVQA_MAX_LAYERS * fuse_tiles * 4, c->s));
     // ragged arch1 batches (or lengths known only on the device): the products pick their split-K depth from nrows[s] on
     // the device -- a level with 2 of 8 row tiles active runs 16 short K slices instead of 4 long ones; the launch's workgroups are
     // re-dealt over (active row tile, column tile, slice).  NVQA_BWD_ZADAPT=0 switches it off.
     static const bool zad_on = [] { const char *e = getenv("NVQA_BWD_ZADAPT"); return !(e && e[0] == '0'); }();
-    const bool zad = zad_on && d.arch == NVQA_ARCH1 && !c->batch_uniform && !ring && !fuse && (4 * R) % (NVQA_BWD_ZMAX * 32) == 0;
+    const bool zad = zad_on && d.arch == NVQA_ARCH1 && !c->batch_uniform && (4 * R) % (NVQA_BWD_ZMAX * 32) == 0;
     const int Zl = zad ? NVQA_BWD_ZMAX : NVQA_BWD_Z;
     for (int dg = 0; dg < TS + L - 1; ++dg) {
         // diagonal dg: layer l (from the top: j = L-1-l) at step s = TS-1 - (dg - j).
@@ -779,11 +745,9 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
         BwdFinish fin;
         fin.Z = NVQA_BWD_Z; fin.B = B; fin.R = R; fin.zadapt = zad ? NVQA_BWD_ZMAX : 0; fin.xcd2d = 0;
         int np = 0, nf = 0;
-        int fin_of[NVQA_MULTI_MAX] = {}, nprod[NVQA_MAX_LAYERS] = {};
         double flops = 0, bytes = 0;
         const size_t slab = (size_t)B * R;
-        // stride between the K slices' slabs: [B][R] row-major, or (fused) whole tiles in the products' register order
-        const size_t slab_st = fuse ? (size_t)fuse_tiles * CfgBwdLevel::BM * CfgBwdLevel::BN : slab;
+        const size_t slab_st = slab; // stride between the K slices' slabs: [B][R] row-major
         for (int l = L - 1; l >= 0; --l) {
             const int s = TS - 1 - (dg - (L - 1 - l));
             if (s < 0 || s >= TS) continue;
@@ -808,17 +772,13 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
             if (!last) {
                 ma.g[np] = mkargs(c->Gt[l] + (size_t)(s + 1) * B * 4 * R, 4 * R, c->P + c->lo.w_h2h[l], R, B, R, 4 * R,
                                   4 * R / NVQA_BWD_Z, 0, c->nrows + s);
-                if (ring) { ma.g[np].B = c->WT + ((size_t)l * 2 + 0) * wt; ma.g[np].ldb = 4 * R; }
                 ma.e[np] = EpiStore{srec, R, slab_st};
-                fin_of[np] = nf; ++nprod[nf];
                 ++np;
             }
             if (!top) {
                 ma.g[np] = mkargs(c->Gt[l + 1] + (size_t)s * B * 4 * R, 4 * R, c->P + c->lo.w_i2h[l + 1], R, B, R, 4 * R,
                                   4 * R / NVQA_BWD_Z, 0, c->nrows + s);
-                if (ring) { ma.g[np].B = c->WT + ((size_t)(l + 1) * 2 + 1) * wt; ma.g[np].ldb = 4 * R; }
                 ma.e[np] = EpiStore{sup, R, slab_st};
-                fin_of[np] = nf; ++nprod[nf];
                 ++np;
             }
             const double nseg = (last ? 0 : 1) + (top ? 0 : 1);
@@ -835,38 +795,16 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
             static const int bmap = [] { const char *e = getenv("NVQA_BWD_MAP"); return e ? atoi(e) : 3; }();
             const bool grid2d = ((R + CfgBwdLevel::BN - 1) / CfgBwdLevel::BN) % 4 == 0 && ((B + CfgBwdLevel::BM - 1) / CfgBwdLevel::BM) % 2 == 0;
             ma.xcd = bmap == 3 && grid2d && !zad ? 3 : xcd_order();
-            if (fuse) { // products + slab sums + cell backward in one launch (lstm_bwd_level.h)
-                MultiArgs<EpiSlabTile> ms;
-                BwdFuse f;
-                f.fin = fin;
-                for (int p = 0; p < np; ++p) {
-                    ms.g[p] = ma.g[p];
-                    ms.e[p] = EpiSlabTile{ma.e[p].C, ma.e[p].slab, (unsigned)(CfgBwdLevel::BM * CfgBwdLevel::BN), (unsigned)(NVQA_BWD_Z * slab_st * 4)};
-                    f.fin_of[p] = fin_of[p];
-                }
-                for (int i = 0; i < nf; ++i) f.target[i] = (unsigned)(NVQA_BWD_Z * nprod[i]);
-                f.cnt = c->bwd_cnt + (size_t)dg * NVQA_MAX_LAYERS * fuse_tiles;
-                ms.zsplit = ma.zsplit; ms.xcd = ma.xcd;
-                if (c->bf16) NVQA_HIP((launch_gemm_bwd_level<WithBF<CfgBwdLevel>::type, A_KC, B_NC>(c->s, ms, np, f)));
-                else NVQA_HIP((launch_gemm_bwd_level<CfgBwdLevel, A_KC, B_NC>(c->s, ms, np, f)));
-            } else if (ring) NVQA_HIP((launch_gemm_ring_multi<false, EpiStore, 0>(c->s, ma, np)));
-            else if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgBwdLevel>::type, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
+            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgBwdLevel>::type, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
             else NVQA_HIP((launch_gemm_multi<CfgBwdLevel, A_KC, B_NC, false, EpiStore, 0>(c->s, ma, np)));
         }
         {
-            // the separate finisher: every cell problem of the level, or (fused levels) only those without a product --
-            // the top layer at the last step
+            // the finisher: slab sums + fused cell backward of every cell problem of the level
             BwdFinish rest = fin;
             rest.xcd2d = (np > 0 && ma.xcd == 3 && R % 4 == 0 && B % 2 == 0 && ((size_t)B * R / 8) % 256 == 0) ? 1 : 0;
-            int nr = nf;
-            if (fuse) {
-                nr = 0;
-                for (int i = 0; i < nf; ++i)
-                    if (nprod[i] == 0) { rest.e[nr] = fin.e[i]; rest.srec[nr] = nullptr; rest.sup[nr] = nullptr; ++nr; }
-            }
-            if (nr > 0) {
-                ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nr * slab * (2.0 * NVQA_BWD_Z + 14) * 4);
-                hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nr), dim3(256), 0, c->s, rest);
+            if (nf > 0) {
+                ProfScope ps(c, PF_LSTM_BWD_FIN, 0, (double)nf * slab * (2.0 * NVQA_BWD_Z + 14) * 4);
+                hipLaunchKernelGGL(k_lstm_bwd_finish, dim3((unsigned)((slab + 255) / 256), nf), dim3(256), 0, c->s, rest);
             }
         }
         NVQA_HIP(hipGetLastError());

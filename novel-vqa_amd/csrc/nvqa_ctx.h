@@ -48,7 +48,7 @@ enum ProfId {
     PF_ALLREDUCE,
     PF_GATHER,
     PF_LSTM_BWD_FIN, // slab sum + fused cell backward of one BPTT level
-    PF_TRANSPOSE,    // W -> W^T copies for the BPTT level products (ring kernel wants K-contiguous operands)
+    PF_TRANSPOSE,    // (unused since round 3: the ring kernel that wanted transposed weights is gone; the id keeps the table stable)
     PF_COUNT
 };
 
@@ -119,11 +119,7 @@ struct nvqa_ctx {
     float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
     float *dqc = nullptr, *dic = nullptr;
     float *colpart = nullptr, *slabs = nullptr;
-    unsigned *bwd_cnt = nullptr;  // arrival counters of the fused BPTT levels (lstm_bwd_level.h)
-    size_t bwd_cnt_words = 0;
-    bool bwd_fuse = false;        // NVQA_BWD_FUSE=1: slab sums + cell backward inside the level kernel (slower: off)
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
-    float *WT = nullptr;          // [L][2][R][4R] transposed W_h2h^l and (l >= 1) W_i2h^l, refreshed every backward pass
     bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate
     bool fold_i2h = true;         // layer-0 input projection as a first K segment of the level kernel; NVQA_FOLD_I2H=0: separate time-batched GEMM
     bool batch_uniform = false;   // current batch: all lengths equal (known on the host)
@@ -136,17 +132,16 @@ struct nvqa_ctx {
     bool wgrad_tr = true;              // bf16 weight gradients on the transposed-read kernel (wgrad_bf16.h)
     float *pb_bias = nullptr;     // [L][RB][4R] LSTM bias-gradient partial sums left by the persistent BPTT kernel
     int pb_bias_rb = 0;           // row blocks of this step's partial sums (0: none: lstm_wgrads runs the column-sum kernels)
-    unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd.h)
+    unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd2.h)
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the sticky err records (forward: words 0-3, BPTT: words 4-7)
     unsigned pf_spin = 0;         // NVQA_PF_SPIN at nvqa_create: polls before a persistent-kernel wait gives up (0: NVQA_PF_SPIN_LIMIT)
     unsigned *pf_sticky = nullptr; // device: first failure of a persistent kernel since the host last looked (persist_fwd.hip: k_err_latch)
     float *dp_status = nullptr, *h_dp_status = nullptr; // data parallel: [0] = ranks whose persistent kernel gave up in this step (summed by the exchange)
-    int persist_bwd_on = -1;       // BPTT as one persistent launch (lstm_persist_bwd.h)
+    int persist_bwd_on = -1;       // BPTT as one persistent launch (lstm_persist_bwd2.h)
     unsigned *pb_cnt = nullptr;   // its counters + err record
     size_t pb_cnt_words = 0;
     float *pb_pup = nullptr;      // [L-1][TS*B][R] products handed from the UP role to the cells of the layer below
-    bool use_ring = false;        // LSTM levels through the LDS-DMA ring kernel (gemm_ring.h); NVQA_RING=0 turns it off
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
     int32_t *mc = nullptr;   // multiple-choice candidates of the batch being evaluated (nvqa_evaluate), allocated on first use

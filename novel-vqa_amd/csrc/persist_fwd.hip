@@ -52,7 +52,7 @@ static int launch_persist_fwd(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 int persist_rows(const nvqa_ctx *c) // row tiles of 16 per workgroup (MT), or 0 when the path does not apply
 {
     const nvqa_dims &d = c->d;
-    if (!c->persist_on || c->use_ring || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
+    if (!c->persist_on || d.R != 512 || !(d.E == 200 || d.E == 512) || d.L > NVQA_PF_MAXL) return 0;
     // (arch2 and equal-length arch1 batches: every row is active whenever any is; ragged arch1 batches: the RAG instance)
     const int NU = d.R / 16;
     for (int MT : {4, 8}) { // the smallest row block that still gives every workgroup its own CU
