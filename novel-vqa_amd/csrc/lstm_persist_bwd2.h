@@ -314,100 +314,111 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
         e_gg[e] = ld(r_g, go + 3u * R * 4);
         e_cp[e] = ld(r_cs, ((srow_g * R + q4) * 4u) | upm);
     };
-    auto fetch_v2 = [&](int h, int s) { // the UP(l, h, s) products of the owned cells (another workgroup's bytes: after its flag, sc1)
+    const int s_head = __builtin_amdgcn_readfirstlane(a.tlast ? *a.tlast : TS - 1); // the step at which dHT enters
+    // v2: what is added to the product before the cell backward.  Below the top layer: the UP(l, h, s) products of the owned cells
+    // (another workgroup's bytes: after its flag, sc1).  Top layer: the head term dHT at the one step where it enters, nothing
+    // otherwise (out-of-range offset: zeros without memory traffic).
+    const __amdgpu_buffer_rsrc_t r_v2 = has_up ? r_p : pf_rsrc(a.dHT, (size_t)L * B * R * 4);
+    auto fetch_v2 = [&](int h, int s) {
+        const bool live_v2 = has_up || (!is_up && s == s_head);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int iloc = eloc(h, e), grow = min(rb + RBn * iloc, B - 1);
-            e_v2[e] = __builtin_bit_cast(pf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       r_p, has_up ? (unsigned)((((size_t)s * B + grow) * R + u0 + 4 * eq) * 4) : PF_OOB, 0, 16));
+            const unsigned off = has_up ? (unsigned)((((size_t)s * B + grow) * R + u0 + 4 * eq) * 4) : (unsigned)((((size_t)l * B + grow) * R + u0 + 4 * eq) * 4);
+            e_v2[e] = __builtin_bit_cast(pf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_v2, live_v2 ? off : PF_OOB, 0, 16));
         }
     };
 
-    const int s_head = __builtin_amdgcn_readfirstlane(a.tlast ? *a.tlast : TS - 1); // the step at which dHT enters
     // ---- reduction of the four K-quarters + cell backward (REC) / tile store (UP) of half-step (h, s) --------------------
-    // prod = false: no product at this half-step (REC at the last step)
-    auto epilogue = [&](auto h_tag, int s, bool prod, int nr) {
+    // Cut in two so that it can be DEFERRED: spill_acc ends a half-step's product (accumulators -> LDS); cell_item finishes one
+    // of the thread's NE items from there.  In the pipelined loop the items of half-step k run behind the first barriers of
+    // half-step k+1 (one item per iteration): done right after the product they cost 2.3 us per half-step of latency -- the
+    // 32 wait states, the LDS round trip through Sred with its own barrier, the read-modify-writes of the carried state --
+    // with the matrix pipe idle; behind the next product's barrier they are ~150 vector instructions per item.
+    auto spill_acc = [&](auto h_tag) {
         constexpr int H = decltype(h_tag)::value, MT = H ? MTB : MTA;
+        pb_nop_before_read();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Sred[(wave * ROWSH + 16 * m + 4 * lh + r) * UNITS + 16 * nt + li] = acc[m][nt][r];
+    };
+    // prod = false: no product at this half-step (REC at the last step)
+    auto cell_item = [&](auto h_tag, auto e_tag, auto imm_tag, int s, bool prod, int nr) {
+        constexpr int H = decltype(h_tag)::value, MT = H ? MTB : MTA, e = decltype(e_tag)::value;
+        constexpr bool IMM = decltype(imm_tag)::value;
+        const int rho = erow + RPP * e, iloc = eloc(H, e), grow = rb + RBn * iloc;
+        if (rho >= 16 * MT || iloc >= nloc || (a.dbg & 2)) return;
+        // Head term: dL/dh of the final state enters at ONE step (arch1: the last; arch2: tmax).  The TOP layer receives it through
+        // the v2 operand (fetch_v2 reads dHT there at that step: a load requested a chunk ahead, on every path).  A layer BELOW
+        // the top has a head term only in arch1 (q = c and h of all layers, 002_train_baseline.lua:306), at s = TS-1, which is
+        // never a pipelined half-step: loaded here in the immediate form only -- a load consumed at once inside the pipelined
+        // loop would drain every prefetch in flight (loads return in order).  (arch2: the host zeroes dHT below the top layer.)
+        pf_f32x4 hx = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (IMM) {
+            if (has_up && s == s_head) hx = *reinterpret_cast<const pf_f32x4 *>(a.dHT + ((size_t)l * B + min(grow, B - 1)) * R + u0 + 4 * eq);
+        }
+        pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (prod) {
-            pb_nop_before_read();
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NTN; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Sred[(wave * ROWSH + 16 * m + 4 * lh + r) * UNITS + 16 * nt + li] = acc[m][nt][r];
+            for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&Sred[(w * ROWSH + rho) * UNITS + 4 * eq]);
         }
+        const size_t srow_g = (size_t)s * B + grow;
+        const unsigned uo = (unsigned)((srow_g * R + u0 + 4 * eq) * 4);
+        if (is_up) {
+            // ship the product, already multiplied by Dropout' of the layer boundary (x 0 or x 1/(1-p): exact, so the cell of
+            // layer l adds the same value it would have formed itself).  The mask hash is a third of the cell backward's
+            // vector instructions; the UP role's epilogue is otherwise one store, and REC(l) sets the pace of the launch.
+            const uint64_t didx = ((((uint64_t)l) * B + esi[H][e]) * TS + s) * R + u0 + 4 * eq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= a.dr.scale(NVQA_SITE_LSTM, didx + j);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v), r_p, uo, 0, 16);
+            return;
+        }
+        const unsigned go = (unsigned)((srow_g * 4 * R + u0 + 4 * eq) * 4);
+        pf_f32x4 dgi = {0.f, 0.f, 0.f, 0.f}, dgf = dgi, dgo = dgi, dgg = dgi, dcn = dgi;
+        pf_f32x4 *dcp = reinterpret_cast<pf_f32x4 *>(dcs + (((tid * 2 + H) * NE + e) * 2) * 4);
+        if (grow < nr) {
+            const pf_f32x4 dc0 = *dcp;
+            const pf_f32x4 ig = e_ig[e], fg = e_fg[e], og = e_og[e], gg = e_gg[e], cc = dcp[1], cp = e_cp[e], v2 = e_v2[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dh = v[j] + v2[j] + hx[j]; // v2: the UP tile, Dropout' applied by its producer (zeros without one)
+                const float tc = pf_tanh(cc[j]);
+                const float dcv = dc0[j] + dh * og[j] * (1.0f - tc * tc);
+                dgi[j] = dcv * gg[j] * ig[j] * (1.0f - ig[j]);
+                dgf[j] = dcv * cp[j] * fg[j] * (1.0f - fg[j]);
+                dgo[j] = dh * tc * og[j] * (1.0f - og[j]);
+                dgg[j] = dcv * ig[j] * (1.0f - gg[j] * gg[j]);
+                dcn[j] = dcv * fg[j];
+            }
+        }
+        *dcp = dcn;
+        dcp[1] = e_cp[e]; // c_{s-1} (slice s of Cs) is the next step's c_s, active row or not
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgi), r_g, go, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgf), r_g, go + (unsigned)R * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgo), r_g, go + 2u * R * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgg), r_g, go + 3u * R * 4, 0, 16);
+        if (grow < nr) { // bias gradient: column sums of dG (own LDS slot: no other thread touches it)
+            pf_f32x4 *bs = reinterpret_cast<pf_f32x4 *>(bsum + tid * 16);
+            bs[0] += dgi; bs[1] += dgf; bs[2] += dgo; bs[3] += dgg;
+        }
+        if constexpr (BF) { // the image the REC / UP products read (the f32 one stays what the weight gradients read)
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            auto img = [&](const pf_f32x4 &x, unsigned gate) {
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pf_pack_bf16(x[0], x[1]), pf_pack_bf16(x[2], x[3])}, r_gb,
+                                                      go / 2 + gate * (unsigned)R * 2, 0, 16);
+            };
+            img(dgi, 0); img(dgf, 1); img(dgo, 2); img(dgg, 3);
+        }
+    };
+    // the immediate form: every item now (the steps without a product; the flush behind the last half-step)
+    auto epilogue = [&](auto h_tag, int s, bool prod, int nr) {
+        if (prod) spill_acc(h_tag);
         __syncthreads();
-        // head term: dL/dh of the final state enters at ONE step (arch1: the last; arch2: tmax): loaded here, in front of every
-        // store of the epilogue, under one wave-uniform branch
-        pf_f32x4 e_hx[NE];
-#pragma unroll
-        for (int e = 0; e < NE; ++e) e_hx[e] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!is_up && s == s_head) {
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int grow = min(rb + RBn * eloc(H, e), B - 1);
-                e_hx[e] = *reinterpret_cast<const pf_f32x4 *>(a.dHT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int rho = erow + RPP * e, iloc = eloc(H, e), grow = rb + RBn * iloc;
-            if (rho >= 16 * MT || iloc >= nloc || (a.dbg & 2)) continue;
-            pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (prod) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&Sred[(w * ROWSH + rho) * UNITS + 4 * eq]);
-            }
-            const size_t srow_g = (size_t)s * B + grow;
-            const unsigned uo = (unsigned)((srow_g * R + u0 + 4 * eq) * 4);
-            if (is_up) {
-                // ship the product, already multiplied by Dropout' of the layer boundary (x 0 or x 1/(1-p): exact, so the cell of
-                // layer l adds the same value it would have formed itself).  The mask hash is a third of the cell backward's
-                // vector instructions; the UP role's epilogue is otherwise one store, and REC(l) sets the pace of the launch.
-                const uint64_t didx = ((((uint64_t)l) * B + esi[H][e]) * TS + s) * R + u0 + 4 * eq;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= a.dr.scale(NVQA_SITE_LSTM, didx + j);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v), r_p, uo, 0, 16);
-                continue;
-            }
-            const unsigned go = (unsigned)((srow_g * 4 * R + u0 + 4 * eq) * 4);
-            pf_f32x4 dgi = {0.f, 0.f, 0.f, 0.f}, dgf = dgi, dgo = dgi, dgg = dgi, dcn = dgi;
-            pf_f32x4 *dcp = reinterpret_cast<pf_f32x4 *>(dcs + (((tid * 2 + H) * NE + e) * 2) * 4);
-            if (grow < nr) {
-                const pf_f32x4 dc0 = *dcp;
-                const pf_f32x4 ig = e_ig[e], fg = e_fg[e], og = e_og[e], gg = e_gg[e], cc = dcp[1], cp = e_cp[e], v2 = e_v2[e], hx = e_hx[e];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float dh = v[j] + v2[j] + hx[j]; // v2: the UP tile, Dropout' applied by its producer (zeros without one)
-                    const float tc = pf_tanh(cc[j]);
-                    const float dcv = dc0[j] + dh * og[j] * (1.0f - tc * tc);
-                    dgi[j] = dcv * gg[j] * ig[j] * (1.0f - ig[j]);
-                    dgf[j] = dcv * cp[j] * fg[j] * (1.0f - fg[j]);
-                    dgo[j] = dh * tc * og[j] * (1.0f - og[j]);
-                    dgg[j] = dcv * ig[j] * (1.0f - gg[j] * gg[j]);
-                    dcn[j] = dcv * fg[j];
-                }
-            }
-            *dcp = dcn;
-            dcp[1] = e_cp[e]; // c_{s-1} (slice s of Cs) is the next step's c_s, active row or not
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgi), r_g, go, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgf), r_g, go + (unsigned)R * 4, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgo), r_g, go + 2u * R * 4, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgg), r_g, go + 3u * R * 4, 0, 16);
-            if (grow < nr) { // bias gradient: column sums of dG (own LDS slot: no other thread touches it)
-                pf_f32x4 *bs = reinterpret_cast<pf_f32x4 *>(bsum + tid * 16);
-                bs[0] += dgi; bs[1] += dgf; bs[2] += dgo; bs[3] += dgg;
-            }
-            if constexpr (BF) { // the image the REC / UP products read (the f32 one stays what the weight gradients read)
-                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                auto img = [&](const pf_f32x4 &x, unsigned gate) {
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pf_pack_bf16(x[0], x[1]), pf_pack_bf16(x[2], x[3])}, r_gb,
-                                                          go / 2 + gate * (unsigned)R * 2, 0, 16);
-                };
-                img(dgi, 0); img(dgf, 1); img(dgo, 2); img(dgg, 3);
-            }
-        }
+        [&]<int... E>(std::integer_sequence<int, E...>) { (cell_item(h_tag, std::integral_constant<int, E>{}, std::true_type{}, s, prod, nr), ...); }(std::make_integer_sequence<int, NE>{});
     };
     auto signal_now = [&](int k) { // not deferred: drain, barrier, one add
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -434,6 +445,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     unsigned n = 0;       // running chunk counter: ring stage = n % NST
     unsigned pend = 0, pend_up = 0;
     int pub = -1;         // half-step whose stores are issued but not yet drained and signalled
+    int pend_k = -1, pend_nr = 0; // half-step whose product sits in Sred, its items still to run (and its nrows[s])
     if (k0 < KN) {
         // pipeline prologue for half-step k0 (half 0): counter, chunks 0 .. D-1, chunk 0 -> LDS, first fragments
         if (!(a.dbg & 1)) (void)pf_wait_ge(need_word(k0), (unsigned)a.NU, a.err, (is_up ? 0x400u : 0x300u) + l, a.spin_limit);
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             // A tile's fragments are refilled right after its tile-group (from the next group of the chunk, or -- last group --
             // from chunk q+1, which the barrier behind tile-group TGB has published); the other tiles' MFMAs cover the read.
             constexpr int NW = BF ? 1 : 4, NTG = GPC * MT, G = NTG * NW;     // gaps per chunk
-            constexpr int QS = 2;                                            // iteration at whose barrier the previous half-step is signalled
+            constexpr int QS = NE;                                           // iteration at whose barrier the previous half-step is signalled
             constexpr int TGB = (GPC - 1) * MT;                              // the barrier follows this tile-group
             constexpr int GB = (TGB + 1) * NW;                               // gaps in front of the barrier
             constexpr int GC = GB > NW ? GB - NW : GB;                       // ... that carry LDS writes: the last tile-group in front of the
@@ -534,16 +546,17 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
                     };
                     [&]<int... W>(std::integer_sequence<int, W...>) { (quarter(std::integral_constant<int, W>{}), ...); }(std::make_integer_sequence<int, NW>{});
                     if constexpr (TG == TGB) {
-                        // The previous half-step's write-through stores are drained and signalled at the barrier of iteration QS
-                        // (their round trip to memory is longer than a chunk: drained at the first barrier the waves parked there
-                        // for ~1 us per half-step; the consumers have a whole half-step of slack).  Younger than those stores are
-                        // exactly: the NLD loads of every iteration before QS, the cell operands requested at iteration 0 (5 per
-                        // item) and the loads of this iteration issued so far -- a counted wait leaves them in flight.
+                        // Behind the barriers of iterations 0 .. NE-1: one deferred item each of the PREVIOUS half-step (its
+                        // product reached Sred in front of this iteration's barrier at the latest); behind the last of them this
+                        // half-step's cell operands are requested (one register set: the previous items have just consumed
+                        // theirs).  The previous half-step's write-through stores are then drained and signalled at the barrier
+                        // of iteration QS = NE (their round trip to memory is longer than a chunk; the consumers have a whole
+                        // half-step of slack).  Younger than those stores are exactly: the loads of iteration NE-1 issued behind
+                        // its barrier, the 5 NE cell operands, and the loads of iteration NE issued so far -- NLD + 5 NE in all
+                        // (every iteration issues the same loads in the same gaps): a counted wait leaves them in flight.
                         if constexpr (q == QS) {
-                            constexpr int issued = [] { int c = 0; for (int j = 0; j < NLDL; ++j) c += (j * G) / NLDL < GB ? 1 : 0; return c; }();
-                            constexpr int younger = QS * NLD + 5 * NE + issued;
                             static_assert(QS + D < NT, "the iterations up to QS request chunks of this half-step");
-                            if (pub >= 0) pb_wait_vmcnt<(younger < 63 ? younger : 63)>();
+                            if (pub >= 0) pb_wait_vmcnt<(NLD + 5 * NE < 63 ? NLD + 5 * NE : 63)>();
                         }
                         __syncthreads();
                         if constexpr (q == QS) {
@@ -552,10 +565,13 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
                                 pub = -1;
                             }
                         }
-                        if constexpr (q == 0) {
-                            // this half-step's cell operands, a product ahead of their use
+                        if constexpr (q < NE) {
+                            if (pend_k >= 0) cell_item(HNT, std::integral_constant<int, (q < NE ? q : 0)>{}, std::false_type{}, kstep(pend_k), true, pend_nr);
+                        }
+                        if constexpr (q == NE - 1) {
+                            if (pend_k >= 0) { pub = pend_k; pend_k = -1; }
 #pragma unroll
-                            for (int e = 0; e < NE; ++e) fetch(H, s, e);
+                            for (int e = 0; e < NE; ++e) fetch(H, s, e); // consumed behind the first barriers of the NEXT half-step
                         }
                     }
                     // refill the tile's fragments
@@ -571,15 +587,22 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             ++n;
         };
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (iter(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, NT>{});
-        epilogue(HT, s, true, nr);
-        pub = k;
+        spill_acc(HT); // its items run behind the first barriers of the next half-step (or in the flush below)
+        pend_k = k; pend_nr = nr;
     };
 
     for (int k = k0; k < KN; k += 2) {
         half_step(std::integral_constant<int, 0>{}, k);
         half_step(std::integral_constant<int, 1>{}, k + 1);
     }
-    if (pub >= 0) signal_now(pub);
+    if (pub >= 0) signal_now(pub); // (only when the loop did not run its drain iteration)
+    if (pend_k >= 0) { // the last half-step's items: nothing left to hide them behind
+        __syncthreads();
+        const int sp = kstep(pend_k);
+        if (pend_k & 1) [&]<int... E>(std::integer_sequence<int, E...>) { (cell_item(std::integral_constant<int, 1>{}, std::integral_constant<int, E>{}, std::true_type{}, sp, true, pend_nr), ...); }(std::make_integer_sequence<int, NE>{});
+        else [&]<int... E>(std::integer_sequence<int, E...>) { (cell_item(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}, std::true_type{}, sp, true, pend_nr), ...); }(std::make_integer_sequence<int, NE>{});
+        signal_now(pend_k);
+    }
 
     // bias gradients of this (layer, row block, unit tile): the row groups' partial sums added in a fixed order
     if (!is_up && a.bias_part) {

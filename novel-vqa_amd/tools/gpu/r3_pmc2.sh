@@ -5,7 +5,7 @@ TAG=$1; shift
 for e in "$@"; do export "$e"; done
 O=$R/gpurun_out/r3/pmc2_$TAG
 mkdir -p $O
-B="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline"
+B="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline $BENCH_FLAGS"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_IFETCH --output-format csv -d $O/sq -- $B > /dev/null 2> $O/sq.log
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INST_LEVEL_LDS --output-format csv -d $O/ic -- $B > /dev/null 2> $O/ic.log
 cd $R

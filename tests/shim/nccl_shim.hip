@@ -13,14 +13,63 @@
 // link pair (bytes / 150 GB/s, on top of NCCL_SHIM_DELAY_US).  The persistent LSTM kernels of libnvqa need ALL their
 // workgroups resident at once; with this mode tests/test_gpu_dp_fullsize.py runs them next to a collective that holds
 // CUs during the backward pass, which no one-GPU box can do with librccl itself.
+// NCCL_SHIM_SHM = name turns the stand-in into a REAL all-reduce between `world` processes on one machine: the ranks meet
+// in a POSIX shared-memory segment /name; ncclAllReduce is stream-ordered (device -> pinned host, a host function on the
+// stream: own slice into the segment, barrier, sum of all ranks' slices in rank order -- the same bits on every rank --,
+// barrier; pinned host -> device).  Two ranks on ONE GPU (which librccl refuses) then run the library's data-parallel
+// path with DIFFERENT gradients per rank: tests/test_gpu_dp.py checks mean-then-clamp against the oracle's global batch.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
 
 namespace {
-struct ShimComm { int world, rank; long calls; double elems; };
+struct ShmHeader { std::atomic<long> arrive; std::atomic<int> failed; long slot_bytes; };
+struct ShimComm {
+    int world, rank; long calls; double elems;
+    // shared-memory mode
+    ShmHeader *hdr = nullptr; char *slots = nullptr; size_t map_bytes = 0; long barriers = 0;
+    float *h_in = nullptr, *h_out = nullptr; // pinned
+};
 struct Id128 { char b[128]; };
+struct ShmOp { ShimComm *c; size_t count; };
+
+bool shm_barrier(ShimComm *c)
+{
+    const long target = (++c->barriers) * c->world;
+    c->hdr->arrive.fetch_add(1, std::memory_order_acq_rel);
+    const time_t t0 = time(nullptr);
+    while (c->hdr->arrive.load(std::memory_order_acquire) < target) {
+        if (c->hdr->failed.load() || time(nullptr) - t0 > 120) { c->hdr->failed.store(1); return false; }
+        usleep(20);
+    }
+    return true;
+}
+void shm_reduce(void *p)
+{
+    ShmOp *op = static_cast<ShmOp *>(p);
+    ShimComm *c = op->c;
+    const size_t n = op->count;
+    float *mine = reinterpret_cast<float *>(c->slots + (size_t)c->rank * c->hdr->slot_bytes);
+    memcpy(mine, c->h_in, n * 4);
+    if (shm_barrier(c)) {
+        for (size_t i = 0; i < n; ++i) c->h_out[i] = 0.f;
+        for (int r = 0; r < c->world; ++r) { // rank order: every rank forms the same sum
+            const float *src = reinterpret_cast<const float *>(c->slots + (size_t)r * c->hdr->slot_bytes);
+            for (size_t i = 0; i < n; ++i) c->h_out[i] += src[i];
+        }
+        shm_barrier(c); // nobody overwrites its slice before everybody has read it
+    } else {
+        for (size_t i = 0; i < n; ++i) c->h_out[i] = __builtin_nanf(""); // a failed exchange must not look like a result
+    }
+    delete op;
+}
 
 __global__ void k_scale(const float *send, float *recv, size_t n, float world, long delay_ticks)
 {
@@ -66,7 +115,24 @@ int ncclGetUniqueId(void *id) { memset(id, 0x5a, 128); return 0; }
 int ncclCommInitRank(void **comm, int world, Id128, int rank)
 {
     if (!comm || world < 1 || rank < 0 || rank >= world) return 4; // ncclInvalidArgument
-    *comm = new ShimComm{world, rank, 0, 0.0};
+    ShimComm *c = new ShimComm{world, rank, 0, 0.0};
+    const char *name = getenv("NCCL_SHIM_SHM");
+    if (name && name[0]) {
+        const char *mb = getenv("NCCL_SHIM_SHM_MB");
+        const long slot = (mb ? atol(mb) : 64) << 20;
+        c->map_bytes = 4096 + (size_t)world * slot;
+        const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)c->map_bytes) != 0) { delete c; return 1; }
+        void *m = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { delete c; return 1; }
+        c->hdr = static_cast<ShmHeader *>(m); // (a fresh segment is zero-filled: arrive = 0, failed = 0)
+        c->hdr->slot_bytes = slot;
+        c->slots = static_cast<char *>(m) + 4096;
+        if (hipHostMalloc((void **)&c->h_in, slot, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&c->h_out, slot, hipHostMallocDefault) != hipSuccess) { delete c; return 1; }
+    }
+    *comm = c;
     return 0;
 }
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s)
@@ -75,6 +141,12 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
     ShimComm *c = static_cast<ShimComm *>(comm);
     c->calls += 1;
     c->elems += (double)count;
+    if (c->hdr) { // real exchange between processes, stream-ordered
+        if ((long)(count * 4) > c->hdr->slot_bytes) return 4;
+        if (hipMemcpyAsync(c->h_in, send, count * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+        if (hipLaunchHostFunc(s, shm_reduce, new ShmOp{c, count}) != hipSuccess) return 1;
+        return hipMemcpyAsync(recv, c->h_out, count * 4, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : 1;
+    }
     const char *e = getenv("NCCL_SHIM_DELAY_US");
     const long ticks = e ? atol(e) * 100 : 0;
     const char *ec = getenv("NCCL_SHIM_CUS");
@@ -91,7 +163,19 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
                        ticks > 500000 ? 500000 : ticks); // at most 5 ms
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
-int ncclCommDestroy(void *comm) { delete static_cast<ShimComm *>(comm); return 0; }
+int ncclCommDestroy(void *comm)
+{
+    ShimComm *c = static_cast<ShimComm *>(comm);
+    if (c->hdr) {
+        munmap(c->hdr, c->map_bytes);
+        (void)hipHostFree(c->h_in);
+        (void)hipHostFree(c->h_out);
+        const char *name = getenv("NCCL_SHIM_SHM");
+        if (name && c->rank == 0) shm_unlink(name);
+    }
+    delete c;
+    return 0;
+}
 const char *ncclGetErrorString(int rc) { return rc == 0 ? "no error" : rc == 4 ? "invalid argument (nccl_shim)" : "unhandled error (nccl_shim)"; }
 // test-only introspection: number of all-reduce calls and elements seen by a communicator
 long nccl_shim_calls(void *comm) { return static_cast<ShimComm *>(comm)->calls; }
