@@ -42,7 +42,7 @@
 namespace nvqa {
 template <class E> struct EpiTraits; // epilogues.h
 
-enum { A_KC = 0, A_MC = 1, A_IM2COL = 2 };
+enum { A_KC = 0, A_MC = 1, A_IM2COL = 2, A_IM2COLF = 3 }; // A_IM2COLF: A_IM2COL when no K-tile straddles two taps (C_in % BK == 0)
 enum { B_KC = 0, B_NC = 1 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -134,11 +134,14 @@ template <> __device__ __forceinline__ f32x4 mfma_bf16<16>(s16x4 a, s16x4 b, f32
 // BF = 1: bf16 matrix cores.  The LDS images stay f32; the 4 consecutive k a lane reads per q step are rounded
 // to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) and go through ONE v_mfma_f32_16x16x16_bf16 /
 // v_mfma_f32_32x32x8_bf16 (same lane -> (row, k) map as the four f32 MFMAs they replace), f32 accumulate.
-template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0, int DMA_ = 0, int BF_ = 0> struct Cfg {
+// SB = 1: a scheduling barrier keeps the LDS reads of the next q step ahead of the MFMAs of the current one (without it the
+// compiler sinks them below the MFMAs and every q step starts with an exposed LDS round trip)
+// WPE > 0: register budget for WPE waves per SIMD (amdgpu_waves_per_eu), so that two workgroups share a CU
+template <int MF_, int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int PF_, int DBG_ = 0, int DMA_ = 0, int BF_ = 0, int SB_ = 0, int WPE_ = 0> struct Cfg {
     static constexpr int MF = MF_, BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_, PF = PF_;
-    static constexpr int DBG = DBG_, DMA = DMA_, BF = BF_;
+    static constexpr int DBG = DBG_, DMA = DMA_, BF = BF_, SB = SB_, WPE = WPE_;
 };
-template <class C> struct WithBF { typedef Cfg<C::MF, C::BM, C::BN, C::BK, C::WM, C::WN, C::WK, C::PF, C::DBG, C::DMA, 1> type; };
+template <class C> struct WithBF { typedef Cfg<C::MF, C::BM, C::BN, C::BK, C::WM, C::WN, C::WK, C::PF, C::DBG, C::DMA, 1, C::SB, C::WPE> type; };
 
 // Epilogue concept:
 //   plain         : void operator()(int z, int m, int n, float v) const
@@ -162,6 +165,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     constexpr int MF = C::MF, BM = C::BM, BN = C::BN, BK = C::BK, WM = C::WM, WN = C::WN, WK = C::WK,
                   PF = C::PF;
     constexpr int NT = 64 * WM * WN * WK;
+    constexpr bool IM = AMODE == A_IM2COL || AMODE == A_IM2COLF, IMF = AMODE == A_IM2COLF;
     constexpr int KI = 64 / MF;        // k per MFMA (lane groups h = 0..KI-1)
     constexpr int QK = 4 * KI;         // k per "q step": 4 MFMAs, k(q,w,h) = QK*q + 4*h + w
     constexpr int NQ = BK / QK;        // q steps per K-tile
@@ -337,19 +341,30 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
 
     // A_IM2COL: output pixel (n, y, x) of each staged row, decomposed ONCE (rows do not change over the K
     // loop); imP = address of that pixel's channel 0 in the NHWC input, NULL for rows beyond the image batch
-    const float *imP[AMODE == A_IM2COL ? NA : 1];
-    int imY[AMODE == A_IM2COL ? NA : 1], imX[AMODE == A_IM2COL ? NA : 1];
-    if constexpr (AMODE == A_IM2COL) {
+    const float *imP[IM ? NA : 1];
+    int imY[IM && !IMF ? NA : 1], imX[IM && !IMF ? NA : 1];
+    // fast path (a K-tile never straddles two taps: C_in % BK == 0, every VGG layer but the first): the tap of a tile is
+    // uniform, so (ky, kx, channel offset) live in scalar registers, advanced tile by tile, and a row's share of the work is
+    // one bit test against imMask (bit t: tap t of this output pixel lies inside the image) and one add
+    unsigned imMask[IMF ? NA : 1];
+    constexpr bool imFast = AMODE == A_IM2COLF; // the launcher checked g.cC % BK == 0 (then K = 9 C_in and the K slices are whole tiles too)
+    int imTap = 0, imC0 = 0; // of the NEXT tile load_tiles is asked for (tiles are requested in order)
+    if constexpr (IM) {
+        imTap = kbeg / g.cC; imC0 = kbeg - imTap * g.cC;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int f = tid + j * NT;
             const int m = m0 + f / (BK / 4);
-            imP[j] = nullptr; imY[j] = 0; imX[j] = 0;
+            imP[j] = nullptr;
+            if constexpr (IMF) imMask[j] = 0; else { imY[j] = 0; imX[j] = 0; }
             if ((A_F4 % NT == 0 || f < A_F4) && m < mlim) {
                 const int hw = g.cH * g.cW;
                 const int n = m / hw, rem = m - n * hw, y = rem / g.cW, x = rem - y * g.cW;
-                imY[j] = y; imX[j] = x;
                 imP[j] = g.A + (((size_t)n * g.cH + y) * g.cW + x) * g.cC;
+                if constexpr (!IMF) { imY[j] = y; imX[j] = x; }
+                const unsigned rows = (y >= 1 ? 1u : 0u) | 2u | (y + 1 < g.cH ? 4u : 0u);
+                const unsigned cols = (x >= 1 ? 1u : 0u) | 2u | (x + 1 < g.cW ? 4u : 0u);
+                if constexpr (IMF) imMask[j] = ((rows & 1u) ? cols : 0u) | (cols << 3) | ((rows & 4u) ? cols << 6 : 0u);
             }
         }
     }
@@ -378,11 +393,27 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         }
         const int glda = s2 ? g.lda2 : g.lda, gldb = s2 ? g.ldb2 : g.ldb;
         int tap0 = 0, cK0 = 0;
-        if constexpr (AMODE == A_IM2COL) { tap0 = k0 / g.cC; cK0 = k0 - tap0 * g.cC; }
+        if constexpr (IM) {
+            if constexpr (imFast) {
+                // uniform: tap and first channel of this tile, then the state of the next one
+                const int tap = imTap, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+                const ptrdiff_t off = ((ptrdiff_t)(ky - 1) * g.cW + (kx - 1)) * g.cC + imC0;
+                imC0 += BK;
+                if (imC0 >= g.cC) { imC0 = 0; ++imTap; }
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    // branch-free: a row outside the image reads a harmless address and is zeroed by a select
+                    const bool ok = (imMask[j] >> tap) & 1u;
+                    const float4 t = *reinterpret_cast<const float4 *>(ok ? imP[j] + off + kA[j] : g.A);
+                    ra[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else { tap0 = k0 / g.cC; cK0 = k0 - tap0 * g.cC; }
+        }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
+            if constexpr (imFast) break;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (AMODE == A_IM2COL) {
+            if constexpr (IM) {
                 // k -> (tap, channel): k0 is uniform, so the division by the channel count is done once per tile;
                 // a staged float4 crosses into the next tap(s) only when a tap is narrower than the tile (C_in < BK)
                 int ci = cK0 + kA[j], tap = tap0;
@@ -403,7 +434,11 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         for (int j = 0; j < NB; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *p = SEG > 0 && s2 ? pB[NSEG - 1][j] : pB[0][j];
-            if (p && k0 + kB[j] < kend)
+            if constexpr (IM) { // the convolutions: unconditional load + select instead of a branch per load
+                const bool ok = p && k0 + kB[j] < kend;
+                const float4 t = *reinterpret_cast<const float4 *>(ok ? (BMODE == B_KC ? p + k0 : p + (size_t)k0 * gldb) : g.B);
+                if (ok) v = t;
+            } else if (p && k0 + kB[j] < kend)
                 v = *reinterpret_cast<const float4 *>(BMODE == B_KC ? p + k0 : p + (size_t)k0 * gldb);
             rb[j] = v;
         }
@@ -462,6 +497,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
 #pragma unroll
         for (int qq = 0; qq < QPW; ++qq) {
             if (qq + 1 < QPW) read_frags(As, Bs, wk * QPW + qq + 1, a[(qq + 1) & 1], b[(qq + 1) & 1]);
+            if constexpr (C::SB != 0) __builtin_amdgcn_sched_barrier(0); // the reads of q step qq+1 stay ahead of the MFMAs of qq
             if constexpr (C::BF != 0) {
                 s16x4 ap[NTM], bp[NTN];
 #pragma unroll
@@ -692,7 +728,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
 }
 
 template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG = 0>
-__global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) void gemm_f32_kernel(GemmArgs g, Epi epi)
+__global__ __launch_bounds__(64 * C::WM * C::WN * C::WK) __attribute__((amdgpu_waves_per_eu(C::WPE > 0 ? C::WPE : 1, C::WPE > 0 ? C::WPE : 8)))
+void gemm_f32_kernel(GemmArgs g, Epi epi)
 {
     if (g.xcd) {
         const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;

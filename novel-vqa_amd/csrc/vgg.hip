@@ -152,8 +152,15 @@ __global__ void k_vgg_preprocess(const float *in, int n, int H, int W, int S, fl
     out[i] = __fsub_rn(rounded(__fmul_rn(v, 255.0f)), mean);
 }
 
-typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgConv;   // C_out >= 128: 8 waves of 32 x 64, 16x16x4 MFMA (tools/kbench3: 117 vs 95 TF for the K-contiguous x K-contiguous form)
-typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1> CfgConv64;  // C_out <= 64
+// C_out >= 128: 8 waves of 32 x 64, 16x16x4 MFMA (tools/kbench3: 117 vs 95 TF for the K-contiguous x K-contiguous form).
+// K-tiles of 64 (round 3; 32 before): the per-tile cost outside the MFMAs -- loads, address selects, LDS writes, two barriers --
+// is paid half as often; two workgroups of 64 KB still share a CU
+// Round 3: SB (the fragment reads of the next q step pinned ahead of the MFMAs) + the A_IM2COLF loader; measured per layer
+// at batch 64 (rocprofv3 kernel trace): 19.0 -> 17.9 ms for the 13 convolutions, 0.66 -> 0.70 of the f32 MFMA peak
+// (K-tiles of 64 -- half the barriers, but 164 registers and one workgroup per CU -- measured 18.9 ms: not used).
+typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1, 0, 0, 0, 1> CfgConv;
+typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 0, 1> CfgConv64;       // C_out <= 64, or too few 128 x 128 tiles for the chip
+typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 0, 0> CfgConvFirst;    // conv1_1 (C_in = 3 -> 4: the general loader; K = 36)
 typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgFc;
 
 } // namespace
@@ -170,6 +177,12 @@ struct nvqa_vgg {
     size_t act_floats = 0;
     bool have_weights = false;
     bool bf16 = false; // nvqa_vgg16_set_precision: operands of every convolution / fc product rounded to bf16, f32 accumulate
+    // host images -> device in CHUNKS on a copy stream, chunk k+1 travelling while the network runs on chunk k
+    // (001_prepro_img_vgg.lua:101-113 copies image by image and then forwards the batch)
+    hipStream_t sc = nullptr;
+    hipEvent_t evCopy[2] = {}, evDone = nullptr; // chunk on the device / last forward finished with v->img
+    bool done_rec = false;
+    int chunk = 256; // measured at B = 512 (configs[4]): one shot 142.0 ms, chunks of 256 140.1, of 128 143.2 (smaller launches fill the chip worse)
 };
 
 static int vgg_layout(nvqa_vgg *v)
@@ -214,6 +227,12 @@ extern "C" int nvqa_vgg16_create(int device, int width_div, int input_hw, int ma
     v->device = device; v->div = width_div; v->hw = input_hw; v->max_batch = max_batch;
     vgg_layout(v);
     NVQA_HIP(hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking));
+    NVQA_HIP(hipStreamCreateWithFlags(&v->sc, hipStreamNonBlocking));
+    for (int p = 0; p < 2; ++p) {
+        NVQA_HIP(hipEventCreateWithFlags(&v->evCopy[p], hipEventDisableTiming));
+    }
+    NVQA_HIP(hipEventCreateWithFlags(&v->evDone, hipEventDisableTiming));
+    { const char *e = getenv("NVQA_VGG_CHUNK"); if (e && atoi(e) > 0) v->chunk = atoi(e); }
     for (int i = 0; i < 13; ++i) {
         NVQA_HIP(hipMalloc((void **)&v->Wc[i], (size_t)v->cout[i] * 9 * v->cinp[i] * 4));
         NVQA_HIP(hipMalloc((void **)&v->bc[i], (size_t)v->cout[i] * 4));
@@ -244,6 +263,11 @@ extern "C" int nvqa_vgg16_destroy(nvqa_vgg *v)
     for (int i = 0; i < 13; ++i) { (void)hipFree(v->Wc[i]); (void)hipFree(v->bc[i]); }
     for (int i = 0; i < 2; ++i) { (void)hipFree(v->Wf[i]); (void)hipFree(v->bf[i]); (void)hipFree(v->act[i]); }
     (void)hipFree(v->img); (void)hipFree(v->nhwc_in); (void)hipFree(v->slabs); (void)hipFree(v->fc6o); (void)hipFree(v->fc7o);
+    for (int p = 0; p < 2; ++p) {
+        if (v->evCopy[p]) (void)hipEventDestroy(v->evCopy[p]);
+    }
+    if (v->evDone) (void)hipEventDestroy(v->evDone);
+    if (v->sc) (void)hipStreamDestroy(v->sc);
     (void)hipStreamDestroy(v->s);
     delete v;
     return 0;
@@ -308,17 +332,12 @@ static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, c
     return 0;
 }
 
-// forward of n host images; the post-ReLU fc7 features stay on the device in v->fc7o [n x F]
-static int vgg_forward(nvqa_vgg *v, const float *images, int n)
+// the network on n images that are already on the device (img [n][3][hw][hw]); post-ReLU fc7 features -> out [n x F]
+static int vgg_network(nvqa_vgg *v, const float *img, int n, float *out)
 {
-    if (!v || !images) { set_error("NULL argument"); return -1; }
-    if (!v->have_weights) { set_error("nvqa_vgg16_fc7 before nvqa_vgg16_set_weights"); return -1; }
-    if (n < 1 || n > v->max_batch) { set_error("n=%d outside 1..%d", n, v->max_batch); return -1; }
-    NVQA_HIP(hipSetDevice(v->device));
     int H = v->hw, W = v->hw;
     const size_t px = (size_t)n * H * W;
-    NVQA_HIP(hipMemcpyAsync(v->img, images, px * 3 * 4, hipMemcpyHostToDevice, v->s));
-    hipLaunchKernelGGL(k_nchw_to_nhwc4, dim3((px + 255) / 256), dim3(256), 0, v->s, v->img, n, H, W, reinterpret_cast<float4 *>(v->nhwc_in));
+    hipLaunchKernelGGL(k_nchw_to_nhwc4, dim3((px + 255) / 256), dim3(256), 0, v->s, img, n, H, W, reinterpret_cast<float4 *>(v->nhwc_in));
     const float *cur = v->nhwc_in;
     int which = 0;
     for (int i = 0; i < 13; ++i) {
@@ -332,13 +351,23 @@ static int vgg_forward(nvqa_vgg *v, const float *images, int n)
         // channels must be zero: they are written by nobody, so clear once when padding exists
         const int ldc = v->coutp[i];
         if (ldc != v->cout[i]) NVQA_HIP(hipMemsetAsync(dst, 0, (size_t)g.M * ldc * 4, v->s));
-        if (v->cout[i] > 64) {
-            if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgConv>::type, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
-            else NVQA_HIP((launch_gemm<CfgConv, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
-        } else {
-            if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgConv64>::type, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
-            else NVQA_HIP((launch_gemm<CfgConv64, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, EpiBiasRelu{dst, ldc, v->bc[i]})));
-        }
+        // A_IM2COLF: every K-tile inside one tap (C_in a multiple of the K-tile: all layers of the full-width network but conv1_1)
+        const EpiBiasRelu ep{dst, ldc, v->bc[i]};
+#define NVQA_CONV_GO(CFG)                                                                                              \
+    do {                                                                                                               \
+        const bool fast = v->cinp[i] % CFG::BK == 0;                                                                   \
+        if (v->bf16 && fast) NVQA_HIP((launch_gemm<WithBF<CFG>::type, A_IM2COLF, B_KC, false, EpiBiasRelu>(v->s, g, ep))); \
+        else if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CFG>::type, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, ep)));  \
+        else if (fast) NVQA_HIP((launch_gemm<CFG, A_IM2COLF, B_KC, false, EpiBiasRelu>(v->s, g, ep)));                  \
+        else NVQA_HIP((launch_gemm<CFG, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, ep)));                             \
+    } while (0)
+        // 128 x 128 tiles when they fill the chip twice over (two workgroups share a CU), 128 x 64 otherwise (conv5 at batch 32:
+        // 49 row tiles x 4 = 196 workgroups on 256 CUs)
+        const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+        if (v->cinp[i] % 32 != 0 && v->cout[i] <= 64) NVQA_CONV_GO(CfgConvFirst);
+        else if (v->cout[i] > 64 && tiles128 >= 512) NVQA_CONV_GO(CfgConv);
+        else NVQA_CONV_GO(CfgConv64);
+#undef NVQA_CONV_GO
         cur = dst; which ^= 1;
         if (kPoolAfter[i]) {
             float *pd = v->act[which];
@@ -351,7 +380,43 @@ static int vgg_forward(nvqa_vgg *v, const float *images, int n)
     NVQA_HIP(hipGetLastError());
     const int c5p = (v->c5 + 3) / 4 * 4;
     NVQA_TRY(fc_layer(v, cur, n, v->s5 * v->s5 * c5p, v->Wf[0], v->bf[0], v->fc6o)); // fc6 + ReLU (Dropout = identity)
-    NVQA_TRY(fc_layer(v, v->fc6o, n, v->F, v->Wf[1], v->bf[1], v->fc7o));              // fc7 + ReLU -> module 38
+    NVQA_TRY(fc_layer(v, v->fc6o, n, v->F, v->Wf[1], v->bf[1], out));                  // fc7 + ReLU -> module 38
+    return 0;
+}
+
+// forward of n host images; the post-ReLU fc7 features stay on the device in v->fc7o [n x F].
+// Up to one chunk: one copy, one pass.  More: chunks of v->chunk images (NVQA_VGG_CHUNK), the copy of chunk k+1 on the copy
+// stream under the network on chunk k, so that of the 0.6 MB per image only the first chunk's transfer is exposed.
+static int vgg_forward(nvqa_vgg *v, const float *images, int n)
+{
+    if (!v || !images) { set_error("NULL argument"); return -1; }
+    if (!v->have_weights) { set_error("nvqa_vgg16_fc7 before nvqa_vgg16_set_weights"); return -1; }
+    if (n < 1 || n > v->max_batch) { set_error("n=%d outside 1..%d", n, v->max_batch); return -1; }
+    NVQA_HIP(hipSetDevice(v->device));
+    const size_t per = (size_t)3 * v->hw * v->hw;
+    if (n <= v->chunk) {
+        NVQA_HIP(hipMemcpyAsync(v->img, images, (size_t)n * per * 4, hipMemcpyHostToDevice, v->s));
+        NVQA_TRY(vgg_network(v, v->img, n, v->fc7o));
+        NVQA_HIP(hipEventRecord(v->evDone, v->s));
+        v->done_rec = true;
+        return 0;
+    }
+    // v->img is written chunk by chunk below: the previous call's network must have converted all of it
+    if (v->done_rec) NVQA_HIP(hipStreamWaitEvent(v->sc, v->evDone, 0));
+    int c = 0;
+    for (int i0 = 0; i0 < n; i0 += v->chunk, ++c) {
+        const int m = std::min(v->chunk, n - i0), p = c & 1;
+        // the caller's memory is pageable: the runtime stages it through its own pinned buffers and returns when the chunk
+        // has left the host (the network on the chunks before it is already queued and runs meanwhile).  A staging copy
+        // of our own (memcpy into hipHostMalloc'ed buffers) measured slower: the single-threaded memcpy of 308 MB takes
+        // as long as the whole bf16 extractor.
+        NVQA_HIP(hipMemcpyAsync(v->img + (size_t)i0 * per, images + (size_t)i0 * per, (size_t)m * per * 4, hipMemcpyHostToDevice, v->sc));
+        NVQA_HIP(hipEventRecord(v->evCopy[p], v->sc));
+        NVQA_HIP(hipStreamWaitEvent(v->s, v->evCopy[p], 0));
+        NVQA_TRY(vgg_network(v, v->img + (size_t)i0 * per, m, v->fc7o + (size_t)i0 * v->F));
+    }
+    NVQA_HIP(hipEventRecord(v->evDone, v->s));
+    v->done_rec = true;
     return 0;
 }
 

@@ -17,6 +17,7 @@ import __graft_entry__ as ge  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
     pkg = ge.load_package()
     v = pkg.binding.Vgg16(0, 1, 224, max_batch=n)
     rng = np.random.default_rng(0)
@@ -28,6 +29,8 @@ def main():
     for k in (25088, 4096):
         parts += [rng.standard_normal(4096 * k).astype(np.float32) * np.sqrt(2.0 / k), np.zeros(4096, np.float32)]
     v.set_weights(np.concatenate(parts))
+    if bf16:
+        v.set_precision(1)
     x = rng.uniform(-120, 130, (n, 3, 224, 224)).astype(np.float32)
     v.fc7(x)
     t0 = time.perf_counter()
@@ -35,9 +38,9 @@ def main():
         f = v.fc7(x)
     dt = (time.perf_counter() - t0) / iters
     gflop = 30.93 * n
-    print(json.dumps({"metric": "VGG-16 fc7 images/s (fp32, batch %d, host in / host out)" % n,
+    print(json.dumps({"metric": "VGG-16 fc7 images/s (%s, batch %d, host in / host out)" % ("bf16 operands" if bf16 else "fp32", n),
                       "value": round(n / dt, 1), "unit": "images/s", "ms_per_batch": round(dt * 1e3, 2),
-                      "tflops": round(gflop / dt / 1e3, 1), "frac_of_fp32_mfma_peak": round(gflop / dt / 1e3 / 157.3, 3),
+                      "tflops": round(gflop / dt / 1e3, 1), "frac_of_mfma_peak": round(gflop / dt / 1e3 / (2500.0 if bf16 else 157.3), 3),
                       "nonzero_features": float((f > 0).mean())}))
     v.close()
 

@@ -34,6 +34,24 @@ def test_fc7_matches_oracle(pkg, orc, div, hw, n):
     v.close()
 
 
+def test_fc7_chunked_host_images(pkg, orc, monkeypatch):
+    """More host images than one chunk (NVQA_VGG_CHUNK, default 256): the batch travels chunk by chunk on the copy
+    stream while the network runs on the chunks before it; a ragged last chunk, two calls in a
+    row (the second call's copies wait for the first call's network), then a one-chunk call on the same handle."""
+    monkeypatch.setenv("NVQA_VGG_CHUNK", "3")
+    div, hw, n = 16, 32, 11
+    o = orc.VggOracle(div, hw)
+    w = o.synth_weights()
+    x = np.ascontiguousarray(_images(n, hw, seed=11))
+    y = np.ascontiguousarray(_images(n, hw, seed=12))
+    v = pkg.binding.Vgg16(0, div, hw, max_batch=n)
+    v.set_weights(w)
+    gx, gy, g2 = v.fc7(x), v.fc7(y), v.fc7(x[:2])
+    assert relmax(gx, o.fc7(w, x)) < 1e-4 and relmax(gy, o.fc7(w, y)) < 1e-4
+    assert relmax(g2, gx[:2]) < 1e-5
+    v.close()
+
+
 def test_fc7_bf16_operands(pkg, orc):
     """nvqa_vgg16_set_precision(1): every product of the extractor with both operands rounded to bf16 (f32 accumulate)
     against the oracle's same mode; the result sits at a bf16-sized distance from the f32 features and closer to the
