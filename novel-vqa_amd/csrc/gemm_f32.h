@@ -109,6 +109,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ s16x4 pack_bf16(const float4 &v)
 {
     const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
@@ -131,6 +132,10 @@ template <> __device__ __forceinline__ f32x4 mfma_bf16<16>(s16x4 a, s16x4 b, f32
 // DBG (ablation builds of tools/kbench only): 1 = no global loads, 2 = no MFMA loop, 4 = no epilogue
 // DMA = 1: tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write);
 // two LDS buffers, the next tile's DMA is in flight while the current one is multiplied.
+// BF = 2: both operands are bf16 IN MEMORY, K-contiguous.  Every size, leading dimension and K index of GemmArgs is then in
+// units of TWO bf16 (= one float of storage: the pointers are the bf16 arrays reinterpreted), so the loaders, the LDS images
+// and their swizzle move 16-byte pieces exactly as in f32; BK = 32 such units = 64 k per tile = two v_mfma_f32_16x16x32_bf16
+// per tile pair (MF = 16 only).
 // BF = 1: bf16 matrix cores.  The LDS images stay f32; the 4 consecutive k a lane reads per q step are rounded
 // to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) and go through ONE v_mfma_f32_16x16x16_bf16 /
 // v_mfma_f32_32x32x8_bf16 (same lane -> (row, k) map as the four f32 MFMAs they replace), f32 accumulate.
@@ -179,6 +184,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     static_assert(BK == 32 || BK == 64 || BK == 128, "BK");
     static_assert(NQ % WK == 0 && NREG % WK == 0, "WK must divide the q steps and the accumulator registers");
     static_assert(PF == 1 || PF == 2, "PF");
+    static_assert(C::BF != 2 || (MF == 16 && AMODE != A_MC && BMODE == B_KC && !GATES && SEG == 0), "BF = 2: K-contiguous bf16 operands, 16x16x32 MFMA");
     static_assert(SEG != 2 || !GATES, "SEG 2 is for the plain epilogue");
     // K-contiguous operands: LDS image [rows][BK], chunk-swizzled, read with ds_read_b128.
     // M/N-contiguous operands: LDS image [BK][rows + 4], read with ds_read_b32 (the 4 floats of a
@@ -498,7 +504,18 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
         for (int qq = 0; qq < QPW; ++qq) {
             if (qq + 1 < QPW) read_frags(As, Bs, wk * QPW + qq + 1, a[(qq + 1) & 1], b[(qq + 1) & 1]);
             if constexpr (C::SB != 0) __builtin_amdgcn_sched_barrier(0); // the reads of q step qq+1 stay ahead of the MFMAs of qq
-            if constexpr (C::BF != 0) {
+            if constexpr (C::BF == 2) {
+                // gfx950 form: the LDS images ARE bf16 (a 16-byte piece = 8 consecutive k = one lane's fragment of
+                // v_mfma_f32_16x16x32_bf16: lane (li, lh) holds k = 32 q + 8 lh + 0..7 of row / column li); one MFMA per
+                // tile pair and q step, no conversion
+#pragma unroll
+                for (int ta = 0; ta < NTM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NTN; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qq & 1][ta]),
+                                                                              __builtin_bit_cast(bf16x8, b[qq & 1][tb]), acc[ta][tb], 0, 0, 0);
+                continue;
+            } else if constexpr (C::BF != 0) {
                 s16x4 ap[NTM], bp[NTN];
 #pragma unroll
                 for (int ta = 0; ta < NTM; ++ta) ap[ta] = pack_bf16(a[qq & 1][ta]);

@@ -68,7 +68,11 @@ template <int MTA, int MTB, int NTN, int GPC> struct PersistBwd2Geom {
     static constexpr int BSUM_FLOATS = NVQA_PF_THREADS * 16;
     static constexpr int QPR = UNITS / 4, RPP = NVQA_PF_THREADS / QPR, NE = (ROWSH + RPP - 1) / RPP; // epilogue items per thread and half
     static constexpr int DC_FLOATS = NVQA_PF_THREADS * 2 * NE * 4 * 2; // carried cell gradient + carried cell state
-    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWSH * UNITS + BSUM_FLOATS + DC_FLOATS) * 4;
+    // row stride of the partial tiles: a lane's 4 accumulator rows are 4 apart per lane group, so with a stride of UNITS
+    // (32 or 64 floats) the four lane groups of a ds_write_b32 hit the same 16 banks (r03 PMC: 21 % / 46 % of the kernel's
+    // LDS cycles were bank conflicts); UNITS + 4 moves each lane group 16 banks on and keeps rows 16-byte aligned
+    static constexpr int SROW = UNITS + 4;
+    static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWSH * SROW + BSUM_FLOATS + DC_FLOATS) * 4;
 };
 
 template <int N> __device__ __forceinline__ void pb_wait_vmcnt()
@@ -87,15 +91,15 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     constexpr int D = 2;                       // chunks in flight = staging-register sets
     constexpr int NT = GKT / GPC;              // chunks per half-step
     static_assert(NT >= 4 && NT % D == 0, "static staging-register sets across half-steps; polls are requested 3 chunks before the end");
-    constexpr int ROWSH = GE::ROWSH, NST = GE::NST, STAGE = GE::STAGE, UNITS = GE::UNITS, PPR = GE::PPR, ROWW = GE::ROWW;
+    constexpr int ROWSH = GE::ROWSH, NST = GE::NST, STAGE = GE::STAGE, UNITS = GE::UNITS, PPR = GE::PPR, ROWW = GE::ROWW, SROW = GE::SROW;
     constexpr int ES = BF ? 2 : 4;             // bytes per A element
     constexpr int RPS = NVQA_PF_THREADS / PPR; // rows per staging pass (16 / GPC)
     static_assert(16 % RPS == 0, "a staging pass stays inside one row tile");
     constexpr int NLDA = 16 * MTA / RPS, NLDB = 16 * MTB / RPS, NLDM = NLDA; // loads per thread and chunk
     extern __shared__ __attribute__((aligned(16))) float pb2_smem[];
     float *const ring = pb2_smem;                   // [NST][ROWSH][ROWW]: 16-byte pieces, low 4 bits of the piece index XOR-swizzled by the row
-    float *const Sred = pb2_smem + NST * STAGE;     // [4 waves][ROWSH][UNITS] partial tiles
-    float *const bsum = Sred + 4 * ROWSH * UNITS;   // [thread][4 gates][4 units]: sum of the thread's dG over its rows and all steps
+    float *const Sred = pb2_smem + NST * STAGE;     // [4 waves][ROWSH][SROW] partial tiles
+    float *const bsum = Sred + 4 * ROWSH * SROW;    // [thread][4 gates][4 units]: sum of the thread's dG over its rows and all steps
     float *const dcs = bsum + GE::BSUM_FLOATS;      // [thread][half][item][2][4 units]: the carried cell gradient, and c_s of the step just done (= c_{s-1}
                                                     // of the next one: the thread owns the same cells at every step) -- thread-private slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Sred[(wave * ROWSH + 16 * m + 4 * lh + r) * UNITS + 16 * nt + li] = acc[m][nt][r];
+                for (int r = 0; r < 4; ++r) Sred[(wave * ROWSH + 16 * m + 4 * lh + r) * SROW + 16 * nt + li] = acc[m][nt][r];
     };
     // prod = false: no product at this half-step (REC at the last step)
     auto cell_item = [&](auto h_tag, auto e_tag, auto imm_tag, int s, bool prod, int nr) {
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
         pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (prod) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&Sred[(w * ROWSH + rho) * UNITS + 4 * eq]);
+            for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&Sred[(w * ROWSH + rho) * SROW + 4 * eq]);
         }
         const size_t srow_g = (size_t)s * B + grow;
         const unsigned uo = (unsigned)((srow_g * R + u0 + 4 * eq) * 4);

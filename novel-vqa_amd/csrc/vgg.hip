@@ -37,6 +37,16 @@ struct EpiBiasRelu {
         C[(size_t)m * ldc + n] = fmaxf(v + b[n], 0.0f);
     }
 };
+// the same into a bf16 NHWC activation (gfx950 form of the bf16 mode: the next layer's operand is read as stored)
+struct EpiBiasReluB16 {
+    __bf16 *C;
+    int ldc;
+    const float *b;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v) const
+    {
+        C[(size_t)m * ldc + n] = (__bf16)fmaxf(v + b[n], 0.0f); // round to nearest even, as the on-the-fly conversion of BF = 1
+    }
+};
 struct EpiSlab {
     float *C;
     int ldc;
@@ -74,6 +84,39 @@ __global__ void k_maxpool2_nhwc(const float4 *in, int n, int H, int W, int C4, f
     o.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
     o.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
     out[i] = o;
+}
+
+// the same on bf16 activations, 8 channels (16 bytes) per thread; the maximum of bf16 values is one of them: exact
+__global__ void k_maxpool2_nhwc_b16(const uint4 *in, int n, int H, int W, int C8, uint4 *out)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n * Ho * Wo * C8;
+    if (i >= total) return;
+    const int c = i % C8;
+    size_t p = i / C8;
+    const int x = p % Wo; p /= Wo;
+    const int y = p % Ho; const size_t img = p / Ho;
+    const uint4 *b = in + ((img * H + 2 * y) * W + 2 * x) * C8 + c;
+    const uint4 a0 = b[0], a1 = b[C8], a2 = b[(size_t)W * C8], a3 = b[(size_t)W * C8 + C8];
+    auto mx = [](unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+        auto lo = [](unsigned w) { return __uint_as_float(w << 16); };
+        auto hi = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
+        const float l = fmaxf(fmaxf(lo(p0), lo(p1)), fmaxf(lo(p2), lo(p3)));
+        const float h = fmaxf(fmaxf(hi(p0), hi(p1)), fmaxf(hi(p2), hi(p3)));
+        return (__float_as_uint(h) & 0xffff0000u) | (__float_as_uint(l) >> 16);
+    };
+    uint4 o;
+    o.x = mx(a0.x, a1.x, a2.x, a3.x); o.y = mx(a0.y, a1.y, a2.y, a3.y);
+    o.z = mx(a0.z, a1.z, a2.z, a3.z); o.w = mx(a0.w, a1.w, a2.w, a3.w);
+    out[i] = o;
+}
+
+// f32 -> bf16 image of a weight array (round to nearest even)
+__global__ void k_to_bf16(const float *in, size_t n, __bf16 *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (__bf16)in[i];
 }
 
 // sum of split-K slabs + bias + ReLU (fc6 / fc7)
@@ -162,6 +205,10 @@ typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1, 0, 0, 0, 1> CfgConv;
 typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 0, 1> CfgConv64;       // C_out <= 64, or too few 128 x 128 tiles for the chip
 typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 0, 0> CfgConvFirst;    // conv1_1 (C_in = 3 -> 4: the general loader; K = 36)
 typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1> CfgFc;
+// gfx950 form of the bf16 mode (BF = 2: bf16 operands in memory; K-tiles of 32 storage floats = 64 k)
+typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1, 0, 0, 2, 1> CfgConvB;
+typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 2, 1> CfgConv64B;
+typedef Cfg<16, 64, 64, 32, 2, 2, 2, 1, 0, 0, 2> CfgFcB;
 
 } // namespace
 
@@ -177,6 +224,11 @@ struct nvqa_vgg {
     size_t act_floats = 0;
     bool have_weights = false;
     bool bf16 = false; // nvqa_vgg16_set_precision: operands of every convolution / fc product rounded to bf16, f32 accumulate
+    // gfx950 form of the bf16 mode (g950; every C_in from conv1_2 on and the fc6 width a multiple of 64: the full-width
+    // network): bf16 images of the weights, bf16 NHWC activations written by the epilogues, bf16 LDS images,
+    // v_mfma_f32_16x16x32_bf16.  The values are the ones the BF = 1 form rounds on the fly.  NVQA_VGG_BF16_FORM=1 keeps BF = 1.
+    bool g950 = false;
+    __bf16 *Wc16[13] = {}, *Wf16 = nullptr;
     // host images -> device in CHUNKS on a copy stream, chunk k+1 travelling while the network runs on chunk k
     // (001_prepro_img_vgg.lua:101-113 copies image by image and then forwards the batch)
     hipStream_t sc = nullptr;
@@ -260,7 +312,8 @@ extern "C" int nvqa_vgg16_destroy(nvqa_vgg *v)
     if (!v) return 0;
     (void)hipSetDevice(v->device);
     (void)hipStreamSynchronize(v->s);
-    for (int i = 0; i < 13; ++i) { (void)hipFree(v->Wc[i]); (void)hipFree(v->bc[i]); }
+    for (int i = 0; i < 13; ++i) { (void)hipFree(v->Wc[i]); (void)hipFree(v->bc[i]); if (v->Wc16[i]) (void)hipFree(v->Wc16[i]); }
+    if (v->Wf16) (void)hipFree(v->Wf16);
     for (int i = 0; i < 2; ++i) { (void)hipFree(v->Wf[i]); (void)hipFree(v->bf[i]); (void)hipFree(v->act[i]); }
     (void)hipFree(v->img); (void)hipFree(v->nhwc_in); (void)hipFree(v->slabs); (void)hipFree(v->fc6o); (void)hipFree(v->fc7o);
     for (int p = 0; p < 2; ++p) {
@@ -270,6 +323,22 @@ extern "C" int nvqa_vgg16_destroy(nvqa_vgg *v)
     if (v->sc) (void)hipStreamDestroy(v->sc);
     (void)hipStreamDestroy(v->s);
     delete v;
+    return 0;
+}
+
+// bf16 images of the repacked weights of conv1_2 .. conv5_3 and fc6 (conv1_1 and fc7 read f32 operands: C_in = 3 and an f32 input)
+static int vgg_bf16_images(nvqa_vgg *v)
+{
+    auto conv = [&](const float *src, size_t n, __bf16 **dst) -> int {
+        if (!*dst) NVQA_HIP(hipMalloc((void **)dst, n * 2));
+        hipLaunchKernelGGL(k_to_bf16, dim3((n + 255) / 256), dim3(256), 0, v->s, src, n, *dst);
+        NVQA_HIP(hipGetLastError());
+        return 0;
+    };
+    for (int i = 1; i < 13; ++i) NVQA_TRY(conv(v->Wc[i], (size_t)v->cout[i] * 9 * v->cinp[i], &v->Wc16[i]));
+    const int c5p = (v->c5 + 3) / 4 * 4;
+    NVQA_TRY(conv(v->Wf[0], (size_t)v->F * v->s5 * v->s5 * c5p, &v->Wf16));
+    NVQA_HIP(hipStreamSynchronize(v->s));
     return 0;
 }
 
@@ -306,6 +375,7 @@ extern "C" int nvqa_vgg16_set_weights(nvqa_vgg *v, const float *flat)
         NVQA_HIP(hipMemcpy(v->bf[1], flat + v->b_off[14], (size_t)F * 4, hipMemcpyHostToDevice));
     }
     v->have_weights = true;
+    if (v->g950) NVQA_TRY(vgg_bf16_images(v));
     return 0;
 }
 
@@ -315,9 +385,11 @@ static int xcd_order() // NVQA_XCD=0: natural tile order (A/B measurements)
     return v;
 }
 
-static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, const float *b, float *out)
+// b16: x and W are bf16 arrays (the gfx950 form of fc6); K counts their elements
+static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, const float *b, float *out, bool b16 = false)
 {
     const int N = v->F;
+    if (b16) K /= 2; // storage floats
     int ks = 1;
     while (ks < 16 && (size_t)((M + 63) / 64) * ((N + 63) / 64) * ks < 512 && K / (ks * 2) >= 256) ks *= 2;
     int kslice = ((K + ks - 1) / ks + 31) / 32 * 32;
@@ -325,7 +397,8 @@ static int fc_layer(nvqa_vgg *v, const float *x, int M, int K, const float *W, c
     GemmArgs g = {};
     g.A = x; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kslice = kslice;
     g.xcd = xcd_order();
-    if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgFc>::type, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
+    if (b16) NVQA_HIP((launch_gemm<CfgFcB, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
+    else if (v->bf16) NVQA_HIP((launch_gemm<WithBF<CfgFc>::type, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
     else NVQA_HIP((launch_gemm<CfgFc, A_KC, B_KC, false, EpiSlab>(v->s, g, EpiSlab{v->slabs, N, (size_t)M * N})));
     hipLaunchKernelGGL(k_fc_finish, dim3(((size_t)M * N + 255) / 256), dim3(256), 0, v->s, v->slabs, ks, M, N, b, out);
     NVQA_HIP(hipGetLastError());
@@ -350,6 +423,30 @@ static int vgg_network(nvqa_vgg *v, const float *img, int n, float *out)
         // output channel stride = padded C_out, so that the next layer reads float4 channels; the pad
         // channels must be zero: they are written by nobody, so clear once when padding exists
         const int ldc = v->coutp[i];
+        if (v->g950) {
+            // activations are bf16 NHWC from conv1_1's epilogue on; sizes of the products in storage floats (two bf16)
+            const EpiBiasReluB16 eb{reinterpret_cast<__bf16 *>(dst), ldc, v->bc[i]};
+            const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+            if (i == 0) {
+                NVQA_HIP((launch_gemm<WithBF<CfgConvFirst>::type, A_IM2COL, B_KC, false, EpiBiasReluB16>(v->s, g, eb)));
+            } else {
+                g.B = reinterpret_cast<const float *>(v->Wc16[i]);
+                g.ldb = g.K = g.kslice = 9 * v->cinp[i] / 2;
+                g.cC = v->cinp[i] / 2;
+                if (v->cout[i] > 64 && tiles >= 512) NVQA_HIP((launch_gemm<CfgConvB, A_IM2COLF, B_KC, false, EpiBiasReluB16>(v->s, g, eb)));
+                else NVQA_HIP((launch_gemm<CfgConv64B, A_IM2COLF, B_KC, false, EpiBiasReluB16>(v->s, g, eb)));
+            }
+            cur = dst; which ^= 1;
+            if (kPoolAfter[i]) {
+                float *pd = v->act[which];
+                const size_t total = (size_t)n * (H / 2) * (W / 2) * (ldc / 8);
+                hipLaunchKernelGGL(k_maxpool2_nhwc_b16, dim3((total + 255) / 256), dim3(256), 0, v->s, reinterpret_cast<const uint4 *>(cur), n, H, W,
+                                   ldc / 8, reinterpret_cast<uint4 *>(pd));
+                H /= 2; W /= 2;
+                cur = pd; which ^= 1;
+            }
+            continue;
+        }
         if (ldc != v->cout[i]) NVQA_HIP(hipMemsetAsync(dst, 0, (size_t)g.M * ldc * 4, v->s));
         // A_IM2COLF: every K-tile inside one tap (C_in a multiple of the K-tile: all layers of the full-width network but conv1_1)
         const EpiBiasRelu ep{dst, ldc, v->bc[i]};
@@ -379,7 +476,8 @@ static int vgg_network(nvqa_vgg *v, const float *img, int n, float *out)
     }
     NVQA_HIP(hipGetLastError());
     const int c5p = (v->c5 + 3) / 4 * 4;
-    NVQA_TRY(fc_layer(v, cur, n, v->s5 * v->s5 * c5p, v->Wf[0], v->bf[0], v->fc6o)); // fc6 + ReLU (Dropout = identity)
+    if (v->g950) NVQA_TRY(fc_layer(v, cur, n, v->s5 * v->s5 * c5p, reinterpret_cast<const float *>(v->Wf16), v->bf[0], v->fc6o, true));
+    else NVQA_TRY(fc_layer(v, cur, n, v->s5 * v->s5 * c5p, v->Wf[0], v->bf[0], v->fc6o)); // fc6 + ReLU (Dropout = identity)
     NVQA_TRY(fc_layer(v, v->fc6o, n, v->F, v->Wf[1], v->bf[1], out));                  // fc7 + ReLU -> module 38
     return 0;
 }
@@ -445,6 +543,15 @@ extern "C" int nvqa_vgg16_set_precision(nvqa_vgg *v, int bf16)
     if (!v) { set_error("vgg is NULL"); return -1; }
     if (bf16 != 0 && bf16 != 1) { set_error("precision must be 0 (f32) or 1 (bf16 operands)"); return -1; }
     v->bf16 = bf16 != 0;
+    const char *form = getenv("NVQA_VGG_BF16_FORM"); // read at every call: the tests compare the two forms in one process
+    const bool old_form = form && form[0] == '1';
+    bool ok = v->bf16 && !old_form && (v->s5 * v->s5 * ((v->c5 + 3) / 4 * 4)) % 64 == 0;
+    for (int i = 1; i < 13 && ok; ++i) ok = v->cinp[i] % 64 == 0 && v->coutp[i] == v->cout[i];
+    v->g950 = ok;
+    if (v->g950 && v->have_weights) {
+        NVQA_HIP(hipSetDevice(v->device));
+        NVQA_TRY(vgg_bf16_images(v));
+    }
     return 0;
 }
 

@@ -16,8 +16,8 @@ import sys
 
 GROUPS = [
     ("lstm_step_fwd", lambda n: "k_lstm_fwd_persist" in n or ("gemm_f32_multi_kernel" in n and "EpiLstmFwd" in n)),
-    ("lstm_step_bwd", lambda n: "k_lstm_bwd_persist" in n or "gemm_bwd_level_kernel" in n or ("gemm_f32_multi_kernel" in n and "EpiStore" in n)),
-    ("lstm_bwd_finish", lambda n: "k_lstm_bwd_finish" in n),
+    ("lstm_step_bwd", lambda n: "k_lstm_bwd_persist" in n),
+    ("gemm_head", lambda n: ("gemm_f32_multi_kernel" in n and "EpiStore" in n) or "EpiHeadBwd" in n or "EpiResort" in n),
     ("gemm_wgrad", lambda n: "k_wgrad_bf16" in n or ("gemm_f32_kernel" in n and "128, 128" in n and ", 1, 1, false" in n and "EpiStore" in n)),
     # i2h forward and the classifier's W_o product share a kernel (EpiBias2, K-contiguous x K-contiguous): the
     # time-batched one is the launch with more than a million threads

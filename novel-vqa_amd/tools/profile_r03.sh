@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-2 profile set (run on the GPU box from the repo root): kernel statistics, HBM traffic (FETCH_SIZE / WRITE_SIZE in
-# separate passes, MI355X_MICROARCH.md), matrix-pipe busy cycles, wave-cycle shares.  Results -> gpurun_out/prof_r02/,
-# summaries -> profiles/r02_*.  The program after `--` is python3 itself (no env / bash hop under rocprofv3).
-# usage: profile_r02.sh [tag [bench flags]]   e.g.  profile_r02.sh bf16_arch2 "--arch 2 --bf16"
+# Round-3 profile set (run on the GPU box from the repo root): kernel statistics, HBM traffic (FETCH_SIZE / WRITE_SIZE in
+# separate passes, MI355X_MICROARCH.md), matrix-pipe busy cycles, wave-cycle shares.  Results -> gpurun_out/prof_r03/,
+# summaries -> profiles/r03_*.  The program after `--` is python3 itself (no env / bash hop under rocprofv3).
+# usage: profile_r03.sh [tag [bench flags]]   e.g.  profile_r03.sh bf16_arch2 "--arch 2 --bf16"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r02${1:+_$1}
+O=$R/gpurun_out/prof_r03${1:+_$1}
 mkdir -p $O
 B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary $2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_under_rocprof.json 2> $O/stats.log

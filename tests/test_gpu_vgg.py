@@ -80,6 +80,49 @@ def test_fc7_bf16_operands(pkg, orc):
     v.close()
 
 
+def test_fc7_bf16_gfx950_form(pkg, orc, monkeypatch):
+    """The full-width network in bf16 mode runs the gfx950 form (every C_in from conv1_2 on a multiple of 64): bf16 images of
+    the weights, bf16 NHWC activations written by the convolution epilogues, bf16 LDS images, v_mfma_f32_16x16x32_bf16, a
+    bf16 max pool, fc6 from bf16 operands.  The operand values are the ones the oracle's bf16 mode rounds (rounding when a
+    value is stored = rounding when it is read; max commutes with a monotone rounding), only the summation order differs:
+    same yardstick as test_fc7_bf16_operands, which covers the BF = 1 form at width / 8.  Also: rows are independent of the
+    batch, a ragged batch of 5 spans two 128-row tiles at conv5, and f32 is restored afterwards."""
+    div, hw, n = 1, 64, 5
+    vo = orc.VggOracle(div, hw)
+    w = vo.synth_weights()
+    x = np.random.default_rng(4).uniform(-110, 130, (n, 3, hw, hw)).astype(np.float32)
+    exact = vo.fc7(w, x)
+    vo.set_precision(1)
+    try:
+        ref = vo.fc7(w, x)
+    finally:
+        vo.set_precision(0)
+    v = pkg.binding.Vgg16(0, div, hw, max_batch=n)
+    v.set_precision(1)           # before the weights: the bf16 images are made by set_weights
+    v.set_weights(w)
+    got = v.fc7(x)
+    scale = np.abs(ref).max()
+    err, dist = np.abs(got - ref).max() / scale, np.abs(got - exact).max() / scale
+    from util import record
+    # the yardstick: the BF = 1 form (f32 in memory, rounded on the fly) of the same network on the same input
+    monkeypatch.setenv("NVQA_VGG_BF16_FORM", "1")
+    v.set_precision(1)
+    old = v.fc7(x)
+    monkeypatch.delenv("NVQA_VGG_BF16_FORM")
+    v.set_precision(1)
+    err_old, between = np.abs(old - ref).max() / scale, np.abs(got - old).max() / scale
+    record("vgg_bf16_gfx950_form", {"err_vs_bf16_oracle": float(err), "dist_bf16_vs_f32": float(dist),
+                                    "bf1_form_err_vs_bf16_oracle": float(err_old), "between_forms": float(between)})
+    assert err < 1e-2 and dist > 1e-3 and err < dist and err < 1.5 * err_old and between < 1.5 * err_old, (err, dist, err_old, between)
+    assert np.array_equal(v.fc7(x), got)
+    assert np.abs(v.fc7(x[:2]) - got[:2]).max() / scale < 1e-5
+    v.set_precision(0)
+    assert np.abs(v.fc7(x) - exact).max() / scale < 1e-4
+    v.set_precision(1)           # after the weights: the images are made by set_precision
+    assert np.array_equal(v.fc7(x), got)
+    v.close()
+
+
 @pytest.mark.parametrize("H,W,S", [(480, 640, 224), (100, 150, 224), (100, 300, 224), (50, 70, 64)])
 def test_preprocess_matches_loadim(pkg, orc, H, W, S):
     """loadim on the device (k_vgg_preprocess) against the oracle, BIT-EXACT: Torch's image.scale in both of its branches
