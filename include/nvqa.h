@@ -120,7 +120,7 @@ int nvqa_forward(nvqa_ctx *ctx, int32_t n, const int32_t *tokens, const int32_t 
 /* Evaluate-mode forward with everything the reference's validation and test loops take from it, on the device:
  *  labels [n] (optional, 1-based): *loss_out = mean cross-entropy over the n rows -- validate(),
  *         002_train_baseline.lua:337-381 (arch2: 003_.../002_train_baseline.lua:335-378);
- *  mc_ans [n x n_mc] (optional; 1-based answer ids, 0 = empty slot, n_mc <= 32): mc_argmax_out[i] = the candidate
+ *  mc_ans [n x n_mc] (optional; 1-based answer ids, 0 = empty slot, n_mc <= 64): mc_argmax_out[i] = the candidate
  *         with the highest score, first one on ties, as torch.max over the candidates in slot order gives it --
  *         multiple-choice answers of 004_eval_model.lua:259-271 (MC_ans_test has 18 slots); rows without any
  *         candidate return 0;
