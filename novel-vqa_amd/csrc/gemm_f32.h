@@ -24,7 +24,10 @@
 //
 // Pipeline: register-staged prefetch (PF = 1: next tile in flight while the current one is
 // multiplied, single LDS buffer; PF = 2: two tiles in flight, two LDS buffers, one barrier per
-// tile), fragment reads software-pipelined one q step ahead of the MFMAs.  Cfg::DMA selects a
+// tile), fragment reads software-pipelined one q step ahead of the MFMAs.  (One tile in flight with two LDS buffers -- the
+// next tile stored behind the current tile's MFMAs, one barrier per tile -- was measured in round 3 and is SLOWER than
+// PF = 1 on every product of the step and on the convolutions: weight gradients 0.795 -> 0.832 ms, VGG batch 128
+// 36.2 -> 38.4 ms; the second barrier is cheaper than the second buffer's LDS footprint.)  Cfg::DMA selects a
 // direct global -> LDS variant (global_load_lds_dwordx4, swizzle on the source address); it is
 // bit-identical and measured equal or slower, so it is off.  WK > 1 splits each K-tile over WK wave
 // groups (more waves per SIMD) and sums the partial accumulators through LDS in a fixed order; the

@@ -312,6 +312,7 @@ static int create_impl(nvqa_ctx *c)
         c->num_cus = prop.multiProcessorCount;
         c->pf_cnt_words = ((size_t)L * ((B + 63) / 64) * TS + 4 + 3) / 4 * 4; // counters for the finest row blocking + err word, 16-byte multiple
         NVQA_TRY(dalloc(&c->pf_cnt, c->pf_cnt_words));
+        NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s)); // once: every launch's latch kernel leaves the block zeroed
         NVQA_TRY(dalloc(&c->pf_ts, 2048)); // NVQA_PF_DBG / NVQA_PB_DBG & 32: timestamps of 256 + 256 workgroups
         NVQA_HIP(hipMemsetAsync(c->pf_ts, 0, 2048 * 8, c->s));
         NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 8 * sizeof(unsigned), hipHostMallocDefault));
@@ -324,6 +325,7 @@ static int create_impl(nvqa_ctx *c)
             const size_t rbmax = (B + 63) / 64;
             c->pb_cnt_words = persist_bwd_counter_words(d, (int)TS);
             NVQA_TRY(dalloc(&c->pb_cnt, c->pb_cnt_words));
+            NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
             NVQA_TRY(dalloc(&c->pb_bias, L * rbmax * 4 * R));
             if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
         }
@@ -874,10 +876,12 @@ static bool emb_index_ok(const nvqa_ctx *c, int VT, int NP)
 {
     return c->tok_seg && NP <= NVQA_TI_NPT * NVQA_TI_THREADS && VT <= 65535 && tok_index_lds(VT, NP) <= 160 * 1024 && c->d.E <= 512;
 }
+// (Main stream.  Round 3 tried the side stream behind the forward kernel, under the head's GEMMs: SLOWER -- 3.175 vs 3.144 ms
+// per step, 1.412 vs 1.403 in bf16 arch2: the one-workgroup kernel with its 160 KB of LDS waits for a whole CU to drain and
+// then delays whatever needs that CU next, the persistent BPTT launch in the worst case.)
 static int emb_index_begin(nvqa_ctx *c, int VT, int NP)
 {
     if (!emb_index_ok(c, VT, NP)) return 0;
-    // (main stream: the persistent forward kernel holds every CU, a side stream would only run behind it)
     static bool attr = false;
     if (!attr) { NVQA_HIP(hipFuncSetAttribute((const void *)k_tok_index, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     ProfScope ps(c, PF_ASSEMBLE, 0, 0);
@@ -932,8 +936,8 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
                            c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok);
     }
     NVQA_HIP(hipGetLastError());
-    if (train) NVQA_TRY(emb_index_begin(c, d.V, TB));
     NVQA_TRY(lstm_forward(c, dr));
+    if (train) NVQA_TRY(emb_index_begin(c, d.V, TB));
     {
         ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * (Q + I) * 4);
         hipLaunchKernelGGL(k_head_prep, dim3(B), dim3(256), 0, c->s, c->Cs[0] + (size_t)T * B * R,
@@ -1039,7 +1043,7 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     const int B = d.B, T = d.T, R = d.R, L = d.L, E = d.E, I = d.I, A = d.A, TS = c->TS, TB = TS * B;
     {
         ProfScope ps(c, PF_ASSEMBLE);
-        hipLaunchKernelGGL(k_arch2_tmax, dim3(1), dim3(256), 0, c->s, c->tok, B, T, c->nrows, c->tinfo, c->sort_idx, c->sort_inv);
+        hipLaunchKernelGGL(k_arch2_tmax, dim3(1), dim3(1024), 0, c->s, c->tok, B, T, c->nrows, c->tinfo, c->sort_idx, c->sort_inv);
     }
     {   // x_1 = cnn_projection(fv_im): Linear(I, E), no dropout / non-linearity (:166,308) -> step-0 rows of X0
         ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * E * I, ((double)B * I + (double)E * I) * 4);
@@ -1051,10 +1055,10 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
         hipLaunchKernelGGL(k_arch2_embed, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->tinfo, c->P + c->lo.w_lk, B, T, d.V, E, c->X0, c->ptok);
     }
     NVQA_HIP(hipGetLastError());
-    if (train && !(c->quirks & NVQA_QUIRK_LOOKUP)) NVQA_TRY(emb_index_begin(c, d.V + 1, TB));
     if (c->quirks & NVQA_QUIRK_H0) // top-layer h0 = what the last backward left in the aliased tensor (Encoder_lstm.lua:238-239)
         NVQA_HIP(hipMemcpyAsync(c->Hs[L - 1], c->dHT + (size_t)(L - 1) * B * R, (size_t)B * R * 4, hipMemcpyDeviceToDevice, c->s));
     NVQA_TRY(lstm_forward(c, dr));
+    if (train && !(c->quirks & NVQA_QUIRK_LOOKUP)) NVQA_TRY(emb_index_begin(c, d.V + 1, TB));
     {
         ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * R * 4);
         hipLaunchKernelGGL(k_arch2_head_prep, dim3(B), dim3(256), 0, c->s, c->Hs[L - 1], c->tinfo, B, R, dr, c->qd);

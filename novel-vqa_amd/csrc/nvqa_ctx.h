@@ -125,7 +125,7 @@ struct nvqa_ctx {
     bool batch_uniform = false;   // current batch: all lengths equal (known on the host)
     bool persist_on = false;      // forward LSTM as one persistent weight-stationary launch (lstm_persist.h)
     int num_cus = 0;
-    unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed before every launch)
+    unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed at creation and by the latch kernel behind every launch)
     size_t pf_cnt_words = 0;
     unsigned long long *pf_ts = nullptr; // debug timestamps of the persistent kernels (NVQA_PF_DBG & 32)
     bool img_fwd_valid = false, img_bwd_valid = false; // this step's persistent bf16 kernels wrote act_b16 / dg_b16

@@ -78,7 +78,6 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     double flops = 0;
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * R * ((double)(TS - 1) + (l + 1 < L ? TS : 0));
     ProfScope ps(c, PF_LSTM_BWD, flops, 0);
-    NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
     const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform; // as in lstm_forward_persist
     unsigned *err = c->pb_cnt + c->pb_cnt_words - 4;
     {
@@ -110,7 +109,7 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         }
 #undef NVQA_PB2_GO
     }
-    NVQA_TRY(persist_latch_err(c, err, 4));
+    NVQA_TRY(persist_latch_err(c, c->pb_cnt, c->pb_cnt_words, 4));
     return 0;
 }
 

@@ -7,23 +7,31 @@
 
 namespace nvqa {
 
-// The err record of a launch lives in the counter block, which the memset in front of EVERY launch clears: a step that
-// timed out would be overwritten by the next clean one before an asynchronous trainer loop reads it.  So each launch is
-// followed by this latch: the FIRST failure is copied into a sticky record that only the host clears, once it has reported
-// it (check_persist), and k_rmsprop refuses to apply gradients while a record is set.  dp_status[0] (data parallel) is
-// summed over the ranks at the end of the step, so that every rank skips the update if any rank's kernel gave up.
-__global__ void k_err_latch(const unsigned *err, unsigned *sticky, float *dp_status)
+// The err record of a launch lives in the last 16 bytes of its counter block.  Each launch is followed by this latch, which
+// (1) copies the FIRST failure into a sticky record that only the host clears, once it has reported it (check_persist;
+// k_rmsprop refuses to apply gradients while a record is set; dp_status[0] (data parallel) is summed over the ranks at the
+// end of the step, so that every rank skips the update if any rank's kernel gave up), (2) writes the sticky record
+// straight into the host's pinned copy (a 16-byte D2H copy is a 5 us blit kernel of its own), and (3) ZEROES the counter
+// block for the next launch (the memset in front of every launch was another 5 us fill kernel).  The blocks are zeroed
+// once at creation.
+__global__ void k_err_latch(unsigned *cnt, unsigned words, unsigned *sticky, float *dp_status, unsigned *host_copy)
 {
-    if (threadIdx.x == 0 && err[0] != 0) {
-        if (sticky[0] == 0) { sticky[1] = err[1]; sticky[2] = err[2]; sticky[3] = err[3]; sticky[0] = err[0]; }
-        if (dp_status) dp_status[0] = 1.0f;
+    if (threadIdx.x == 0) {
+        const unsigned *err = cnt + words - 4;
+        if (err[0] != 0) {
+            if (sticky[0] == 0) { sticky[1] = err[1]; sticky[2] = err[2]; sticky[3] = err[3]; sticky[0] = err[0]; }
+            if (dp_status) dp_status[0] = 1.0f;
+        }
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(host_copy + i, sticky[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < words; i += blockDim.x) cnt[i] = 0;
 }
-int persist_latch_err(nvqa_ctx *c, const unsigned *err, int off)
+int persist_latch_err(nvqa_ctx *c, unsigned *cnt, size_t words, int off)
 {
-    hipLaunchKernelGGL(k_err_latch, dim3(1), dim3(64), 0, c->s, err, c->pf_sticky + off, c->comm ? c->dp_status : (float *)nullptr);
+    hipLaunchKernelGGL(k_err_latch, dim3(1), dim3(1024), 0, c->s, cnt, (unsigned)words, c->pf_sticky + off,
+                       c->comm ? c->dp_status : (float *)nullptr, c->h_pf_err + off);
     NVQA_HIP(hipGetLastError());
-    NVQA_HIP(hipMemcpyAsync(c->h_pf_err + off, c->pf_sticky + off, 16, hipMemcpyDeviceToHost, c->s));
     return 0;
 }
 
@@ -114,7 +122,6 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     double flops = 0;
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);
     ProfScope ps(c, PF_LSTM_FWD, flops, 0);
-    NVQA_HIP(hipMemsetAsync(c->pf_cnt, 0, c->pf_cnt_words * 4, c->s));
     // ragged arch1 batch (or lengths known only on the device: the dataset route of a ragged dataset): the instance that
     // skips the MFMAs of row tiles without active rows
     const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform;
@@ -135,7 +142,7 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
         else { if (MT == 4) NVQA_PF_GO(512, 4, false, false); else NVQA_PF_GO(512, 8, false, false); }
     }
 #undef NVQA_PF_GO
-    NVQA_TRY(persist_latch_err(c, a.err, 0));
+    NVQA_TRY(persist_latch_err(c, c->pf_cnt, c->pf_cnt_words, 0));
     return 0;
 }
 
