@@ -74,6 +74,9 @@ typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 // tools/kbench10 (sweep over the head / d(input) / i2h shapes): 8 waves of 16 x 32 (64x64) or 32 x 64 (128x128) with
 // the 16x16x4 MFMA beat the 4-wave 32x32x2 forms by 5-10 % in every layout except the long-K weight gradients
 typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgMed;
+// gfx950 form of a bf16 product (gemm_f32.h BF = 2: both operands bf16 in memory, K-contiguous): d(layer-0 input)
+typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1, 0, 0, 2, 1> CfgDx0B;
+typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 2, 1> CfgDx0B64;
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgBig16;
 typedef Cfg<16, 64, 32, 32, 4, 2, 1, 1> CfgNarrow; // 64 x 32 tiles, 8 waves of 16 x 16: products whose 64 x 64 tiling leaves half the
                                                    // CUs idle (W_o, dzd: 128 tiles; 20 vs 27 us) or whose N wastes wide tiles (d(input), N = 200: 122 vs 140 us)
@@ -381,6 +384,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->pf_ts) (void)hipFree(c->pf_ts);
     if (c->act_b16) (void)hipFree(c->act_b16);
     if (c->dg_b16) (void)hipFree(c->dg_b16);
+    if (c->wi2h0_t16) (void)hipFree(c->wi2h0_t16);
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
     if (c->pb_bias) (void)hipFree(c->pb_bias);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
@@ -846,6 +850,22 @@ static int lstm_wgrads(nvqa_ctx *c, int l)
     return 0;
 }
 
+// W [rows][cols] f32 -> its transpose [cols][rows] in bf16 (round to nearest even), 32 x 32 tiles through LDS
+__global__ void k_transpose_to_bf16(const float *W, int rows, int cols, __bf16 *out)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, cc = c0 + threadIdx.x;
+        t[i][threadIdx.x] = r < rows && cc < cols ? W[(size_t)r * cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int cc = c0 + i, r = r0 + threadIdx.x;
+        if (cc < cols && r < rows) out[(size_t)cc * rows + r] = (__bf16)t[threadIdx.x][i];
+    }
+}
+
 // dL/d(layer-0 input) for all steps at once; runs after the LSTM weight gradients so that their
 // all-reduce (data parallel) overlaps it.
 static int lstm_dx0(nvqa_ctx *c, float *dX0)
@@ -853,6 +873,25 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
     const nvqa_dims &d = c->d;
     const int R = d.R, TB = c->TS * d.B;
     ProfScope ps(c, PF_GEMM_DGRAD, 2.0 * TB * d.E * 4 * R, ((double)TB * (4 * R + d.E) + 4.0 * R * d.E) * 4);
+    // bf16 mode behind the persistent BPTT kernel: dG exists as a bf16 image ([TS*B][4R], K-contiguous); with a transposed
+    // bf16 image of W_i2h (made here, per step: the weights move) both operands are K-contiguous bf16 and the product runs
+    // in the gfx950 form (BF = 2: bf16 LDS images, v_mfma_f32_16x16x32_bf16) instead of rounding f32 LDS images per MFMA.
+    // Same operand values, f32 accumulate, f32 result.  NVQA_DX0_B2=0: the BF = 1 form (A/B runs).
+    static const bool b2_on = [] { const char *e = getenv("NVQA_DX0_B2"); return !(e && e[0] == '0'); }();
+    if (c->bf16 && c->img_bwd_valid && b2_on && (4 * R) % 64 == 0) {
+        if (!c->wi2h0_t16) NVQA_HIP(hipMalloc((void **)&c->wi2h0_t16, (size_t)d.E * 4 * R * 2));
+        hipLaunchKernelGGL(k_transpose_to_bf16, dim3((d.E + 31) / 32, (4 * R + 31) / 32), dim3(32, 8), 0, c->s, c->P + c->lo.w_i2h[0], 4 * R, d.E,
+                           reinterpret_cast<__bf16 *>(c->wi2h0_t16));
+        GemmArgs g = {};
+        g.A = reinterpret_cast<const float *>(c->dg_b16); g.lda = 4 * R / 2; // sizes in storage floats (two bf16)
+        g.B = reinterpret_cast<const float *>(c->wi2h0_t16); g.ldb = 4 * R / 2;
+        g.M = TB; g.N = d.E; g.K = g.kslice = 4 * R / 2;
+        g.mseg_limits = c->nrows; g.seg_rows = d.B;
+        g.xcd = d.arch == NVQA_ARCH1 && !c->batch_uniform ? 0 : xcd_order();
+        if (d.E > 256) NVQA_HIP((launch_gemm<CfgDx0B, A_KC, B_KC, false, EpiStore>(c->s, g, EpiStore{dX0, d.E, 0})));
+        else NVQA_HIP((launch_gemm<CfgDx0B64, A_KC, B_KC, false, EpiStore>(c->s, g, EpiStore{dX0, d.E, 0})));
+        return 0;
+    }
     GemmArgs g = mkargs(c->Gt[0], 4 * R, c->P + c->lo.w_i2h[0], d.E, TB, d.E, 4 * R);
     g.mseg_limits = c->nrows; g.seg_rows = d.B;
     // ragged arch1 batch: the XCD-contiguous tile order would give the early steps (few active rows: their row tiles

@@ -132,6 +132,7 @@ struct nvqa_ctx {
     bool wgrad_tr = true;              // bf16 weight gradients on the transposed-read kernel (wgrad_bf16.h)
     float *pb_bias = nullptr;     // [L][RB][4R] LSTM bias-gradient partial sums left by the persistent BPTT kernel
     int pb_bias_rb = 0;           // row blocks of this step's partial sums (0: none: lstm_wgrads runs the column-sum kernels)
+    unsigned short *wi2h0_t16 = nullptr; // bf16 image of W_i2h[0]^T ([E][4R]) for the gfx950-form d(input) product, remade every step
     unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd2.h)
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the sticky err records (forward: words 0-3, BPTT: words 4-7)
