@@ -433,7 +433,7 @@ static int vgg_network(nvqa_vgg *v, const float *img, int n, float *out)
                 g.B = reinterpret_cast<const float *>(v->Wc16[i]);
                 g.ldb = g.K = g.kslice = 9 * v->cinp[i] / 2;
                 g.cC = v->cinp[i] / 2;
-                if (v->cout[i] > 64 && tiles >= 512) NVQA_HIP((launch_gemm<CfgConvB, A_IM2COLF, B_KC, false, EpiBiasReluB16>(v->s, g, eb)));
+                if (v->cout[i] > 64 && tiles >= 256) NVQA_HIP((launch_gemm<CfgConvB, A_IM2COLF, B_KC, false, EpiBiasReluB16>(v->s, g, eb)));
                 else NVQA_HIP((launch_gemm<CfgConv64B, A_IM2COLF, B_KC, false, EpiBiasReluB16>(v->s, g, eb)));
             }
             cur = dst; which ^= 1;
@@ -458,11 +458,11 @@ static int vgg_network(nvqa_vgg *v, const float *img, int n, float *out)
         else if (fast) NVQA_HIP((launch_gemm<CFG, A_IM2COLF, B_KC, false, EpiBiasRelu>(v->s, g, ep)));                  \
         else NVQA_HIP((launch_gemm<CFG, A_IM2COL, B_KC, false, EpiBiasRelu>(v->s, g, ep)));                             \
     } while (0)
-        // 128 x 128 tiles when they fill the chip twice over (two workgroups share a CU), 128 x 64 otherwise (conv5 at batch 32:
-        // 49 row tiles x 4 = 196 workgroups on 256 CUs)
+        // 128 x 128 tiles when there is at least one per CU, 128 x 64 otherwise (conv5 at batch 32: 49 row tiles x 4 = 196
+        // workgroups on 256 CUs; at batch 64 -- 392 tiles -- the wide tile is the faster one again: 600 vs 645 us)
         const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
         if (v->cinp[i] % 32 != 0 && v->cout[i] <= 64) NVQA_CONV_GO(CfgConvFirst);
-        else if (v->cout[i] > 64 && tiles128 >= 512) NVQA_CONV_GO(CfgConv);
+        else if (v->cout[i] > 64 && tiles128 >= 256) NVQA_CONV_GO(CfgConv);
         else NVQA_CONV_GO(CfgConv64);
 #undef NVQA_CONV_GO
         cur = dst; which ^= 1;
