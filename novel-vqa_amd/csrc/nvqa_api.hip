@@ -73,12 +73,16 @@ static void prof_collect(nvqa_ctx *c)
 typedef Cfg<32, 128, 128, 32, 2, 2, 1, 1> CfgBig;
 // tools/kbench10 (sweep over the head / d(input) / i2h shapes): 8 waves of 16 x 32 (64x64) or 32 x 64 (128x128) with
 // the 16x16x4 MFMA beat the 4-wave 32x32x2 forms by 5-10 % in every layout except the long-K weight gradients
-typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgMed;
+// Round 3: K-tiles of 64 for the 64 x 64 and 64 x 32 configurations (half the barriers and load rounds of these short,
+// latency-bound K loops): head backward 0.137 -> 0.131 ms, d(input) 0.132 -> 0.126, arch2 heads 0.110 -> 0.091, bf16 arch2
+// heads 0.108 -> 0.083; the one product that LOSES is the two-problem forward projection launch (0.098 -> 0.105): CfgMedMulti
+typedef Cfg<16, 64, 64, 64, 4, 2, 1, 1> CfgMed;
+typedef Cfg<16, 64, 64, 32, 4, 2, 1, 1> CfgMedMulti;
 // gfx950 form of a bf16 product (gemm_f32.h BF = 2: both operands bf16 in memory, K-contiguous): d(layer-0 input)
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1, 0, 0, 2, 1> CfgDx0B;
 typedef Cfg<16, 128, 64, 32, 4, 2, 1, 1, 0, 0, 2, 1> CfgDx0B64;
 typedef Cfg<16, 128, 128, 32, 4, 2, 1, 1> CfgBig16;
-typedef Cfg<16, 64, 32, 32, 4, 2, 1, 1> CfgNarrow; // 64 x 32 tiles, 8 waves of 16 x 16: products whose 64 x 64 tiling leaves half the
+typedef Cfg<16, 64, 32, 64, 4, 2, 1, 1> CfgNarrow; // 64 x 32 tiles, 8 waves of 16 x 16: products whose 64 x 64 tiling leaves half the
                                                    // CUs idle (W_o, dzd: 128 tiles; 20 vs 27 us) or whose N wastes wide tiles (d(input), N = 200: 122 vs 140 us)
 #define NVQA_BWD_Z 4 // K slices of the BPTT level products
 #define NVQA_BWD_ZMAX 16 // ... of a ragged batch's levels with few active row tiles (gemm_f32.h zsplit_for)
@@ -997,8 +1001,8 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             ma.g[1] = mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I, I / Zh);
             ma.e[1] = EpiStore{c->slabs + Zh * nBC, C, nBC};
             ma.zsplit = Zh;
-            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMed>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
-            else NVQA_HIP((launch_gemm_multi<CfgMed, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMedMulti>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
+            else NVQA_HIP((launch_gemm_multi<CfgMedMulti, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
                                c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
         } else {
