@@ -324,7 +324,7 @@ static int create_impl(nvqa_ctx *c)
         NVQA_HIP(hipMemsetAsync(c->pf_ts, 0, 2048 * 8, c->s));
         NVQA_HIP(hipHostMalloc((void **)&c->h_pf_err, 8 * sizeof(unsigned), hipHostMallocDefault));
         memset(c->h_pf_err, 0, 32);
-        // persistent BPTT (lstm_persist_bwd2.h / lstm_persist_bwd.h): default where the shape is eligible; NVQA_PERSIST_BWD=0: the
+        // persistent BPTT (lstm_persist_bwd2.h): default where the shape is eligible; NVQA_PERSIST_BWD=0: the
         // per-level kernels
         const char *eb = getenv("NVQA_PERSIST_BWD");
         c->persist_bwd_on = !eb ? -1 : (eb[0] == '1' ? 1 : 0);
@@ -594,7 +594,7 @@ static int wgrad_bf16(nvqa_ctx *c, const float *A, const unsigned short *A16, in
 {
     const int tiles = ((M + NVQA_WB_BM - 1) / NVQA_WB_BM) * ((N + NVQA_WB_BN - 1) / NVQA_WB_BN);
     int ks = 1;
-    while (ks < 16 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2; // tools/kbench15: 2048 x 512: 8 slices, 2048 x 200: 16
+    while (ks < 16 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2; // measured (round 2): 2048 x 512: 8 slices, 2048 x 200: 16
     if ((size_t)ks * M * N > c->slab_floats) ks = std::max<int>(1, (int)(c->slab_floats / ((size_t)M * N)));
     int kslice = ((K + ks - 1) / ks + NVQA_WB_BK - 1) / NVQA_WB_BK * NVQA_WB_BK;
     ks = (K + kslice - 1) / kslice;
@@ -835,14 +835,14 @@ static int lstm_wgrads(nvqa_ctx *c, int l)
     const int R = d.R, TB = c->TS * d.B;
     const int in = l == 0 ? d.E : R;
     const float *Xin = l == 0 ? c->X0 : c->U[l];
-    // bf16 images of the operands, where this step's persistent bf16 kernels left them (lstm_persist.h / lstm_persist_bwd.h)
+    // bf16 images of the operands, where this step's persistent bf16 kernels left them (lstm_persist.h / lstm_persist_bwd2.h)
     const size_t hs = (size_t)(c->TS + 1) * d.B * R, us = (size_t)c->TS * d.B * R;
     const unsigned short *G16 = c->img_bwd_valid ? c->dg_b16 + (size_t)l * TB * 4 * R : nullptr;
     const unsigned short *H16 = c->img_fwd_valid ? c->act_b16 + l * hs : nullptr;
     const unsigned short *X16 = c->img_fwd_valid && l > 0 ? c->act_b16 + d.L * hs + l * us : nullptr;
     NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s, G16, H16));
     NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s, G16, X16));
-    if (c->pb_bias_rb > 0) { // the persistent BPTT kernel of this step left the column sums per row block (lstm_persist_bwd.h)
+    if (c->pb_bias_rb > 0) { // the persistent BPTT kernel of this step left the column sums per row block (lstm_persist_bwd2.h)
         ProfScope ps(c, PF_COLSUM, 0, (double)c->pb_bias_rb * 4 * R * 4);
         hipLaunchKernelGGL(k_bias_sum, dim3((4 * R + 255) / 256), dim3(256), 0, c->s, c->pb_bias + (size_t)l * c->pb_bias_rb * 4 * R, c->pb_bias_rb,
                            4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l]);

@@ -1,5 +1,5 @@
 // persist_host.h -- host-side entry points of the persistent LSTM kernels.  The kernels and their launchers live in
-// their own translation units (persist_fwd.hip: lstm_persist.h; persist_bwd.hip: lstm_persist_bwd.h, lstm_persist_bwd2.h)
+// their own translation units (persist_fwd.hip: lstm_persist.h; persist_bwd.hip: lstm_persist_bwd2.h)
 // so that the library builds in parallel; nvqa_api.hip only calls these.
 #pragma once
 #include "nvqa_ctx.h"

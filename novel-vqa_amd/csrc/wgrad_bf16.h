@@ -10,7 +10,7 @@
 //     16-lane group, delivered column-major): two reads = the 8 k of one v_mfma_f32_16x16x32_bf16 operand;
 //   * image layout (b) of cdna_hip_programming.md T10: 256-byte rows, 16-byte chunk ch of row k at
 //     256 k + 16 (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))): conflict-free for these reads.
-// Where the step's persistent bf16 kernels have left bf16 IMAGES of an operand (dG: lstm_persist_bwd.h's Gb; h and
+// Where the step's persistent bf16 kernels have left bf16 IMAGES of an operand (dG: lstm_persist_bwd2.h's Gb; h and
 // Dropout(h): lstm_persist.h's Hb / Ub -- the same values, rounded the same way) the operand is staged from the image
 // instead (template flags ABF / BBF): half the L2 -> LDS bytes, which bound the f32-sourced form (32 flop per byte at
 // this tile size), and no conversion.

@@ -5,7 +5,7 @@
 
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's matrix pipe is busy, summed over the chip's 1024
 SIMDs (MI355X_MICROARCH.md, cycle-constants table).  Utilisation = busy cycles / (kernel duration x clock x
-1024 SIMDs), with the 2.38 GHz that tools/kbench9 measured inside these kernels (s_memtime / s_memrealtime);
+1024 SIMDs), with the 2.38 GHz that a round-1 microbenchmark (s_memtime against s_memrealtime) measured inside these kernels (s_memtime / s_memrealtime);
 GRBM_GUI_ACTIVE / 8 / duration is printed beside it as the counter-side estimate of the clock."""
 import collections
 import csv
