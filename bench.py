@@ -392,6 +392,9 @@ def main():
                                                "note": "JdJ-shaped entry nvqa_step: host batch validated, staged in pinned memory and copied on the side stream into the device set the running step does not read (8 pre-assembled host batches cycled)"}
         sec["vgg16_fc7"] = bench_vgg(pkg)
         sec["vgg16_fc7_bf16"] = bench_vgg(pkg, bf16=True)
+        # the same call at a batch that fills the chip in the deep layers too (the reference's -batch_size is a script flag)
+        sec["vgg16_fc7_batch128"] = bench_vgg(pkg, n=128, iters=3)
+        sec["vgg16_fc7_bf16_batch128"] = bench_vgg(pkg, n=128, iters=3, bf16=True)
         sec["arch1_end_to_end_vgg16"] = bench_end_to_end(pkg, WORKLOAD, local_rank)
         sec["arch1_end_to_end_vgg16_bf16_extractor"] = bench_end_to_end(pkg, WORKLOAD, local_rank, bf16_vgg=True)
         out["secondary"] = sec
