@@ -4,6 +4,7 @@
 // where the row width allows, no atomics on floats (results are bit-reproducible).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "tok_index.h"
 #include "../../include/nvqa_layout.h"
 #include "epilogues.h"
 #include "gemm_f32.h"
@@ -465,89 +466,10 @@ __global__ void k_emb_bwd(const int32_t *ptok, const float *X, const float *dX, 
 //                 in chunk order.
 // The summation order is fixed by perm and the chunk boundaries, so the result is bit-reproducible; no atomics on data.
 // ---------------------------------------------------------------------------------
-#define NVQA_ES_SHORT 32   // occurrences one wave sums by itself
-#define NVQA_ES_CHUNKS 16  // a longer segment is cut into this many chunks
-#define NVQA_TI_THREADS 1024
-#define NVQA_TI_NPT 16     // packed positions per thread of the index kernel: T*B <= 16384
-__host__ __device__ inline size_t tok_index_lds(int VT, int NP) { return (size_t)VT * 4 + (size_t)NP * 4 + NVQA_TI_THREADS * 4 + 16; }
-__global__ __launch_bounds__(NVQA_TI_THREADS) void k_tok_index(const int32_t *ptok, int NP, int VT, int32_t *seg_start /*[VT+1]*/,
-                                                               uint16_t *perm /*[NP]*/, int32_t *long_tok /*[NP / SHORT + 1]*/,
-                                                               unsigned *done /*[NP / SHORT + 1]*/, int32_t *nlong_out)
+__global__ __launch_bounds__(NVQA_TI_THREADS) void k_tok_index(TokIndexArgs t)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned ti_smem[];
-    unsigned *cnt = ti_smem;              // [VT] counts -> exclusive prefix sums = placement cursors -> segment ENDS
-    unsigned *part = cnt + VT;            // [threads] scan partials
-    unsigned *nlong = part + NVQA_TI_THREADS;
-    unsigned *tmp = nlong + 4;            // [NP] (token << 16 | position), grouped by token, unordered inside a group
-    const int tid = threadIdx.x;
-    int w[NVQA_TI_NPT]; // this thread's tokens: one batch of independent loads
-#pragma unroll
-    for (int i = 0; i < NVQA_TI_NPT; ++i) {
-        const int k = tid + i * NVQA_TI_THREADS;
-        const int x = k < NP ? ptok[k] : -1;
-        w[i] = x >= 0 && x < VT ? x : -1;
-    }
-    for (int v = tid; v < VT; v += NVQA_TI_THREADS) cnt[v] = 0;
-    if (tid == 0) *nlong = 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NVQA_TI_NPT; ++i)
-        if (w[i] >= 0) atomicAdd(&cnt[w[i]], 1u);
-    __syncthreads();
-    // exclusive scan: thread -> a contiguous run of tokens
-    const int per = (VT + NVQA_TI_THREADS - 1) / NVQA_TI_THREADS, v0 = tid * per, v1 = min(VT, v0 + per);
-    unsigned sum = 0;
-    for (int v = v0; v < v1; ++v) sum += cnt[v];
-    // inclusive scan of the 1024 partials: inside each wave by shuffles, then the 16 wave totals
-    unsigned inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned x = __shfl_up(inc, o, 64);
-        if ((tid & 63) >= o) inc += x;
-    }
-    if ((tid & 63) == 63) part[tid >> 6] = inc;
-    __syncthreads();
-    if (tid < 64) {
-        const unsigned t0 = tid < NVQA_TI_THREADS / 64 ? part[tid] : 0u;
-        unsigned t = t0;
-#pragma unroll
-        for (int o = 1; o < NVQA_TI_THREADS / 64; o <<= 1) {
-            const unsigned x = __shfl_up(t, o, 64);
-            if (tid >= o) t += x;
-        }
-        if (tid < NVQA_TI_THREADS / 64) part[64 + tid] = t - t0; // exclusive prefix of the wave totals
-        if (tid == NVQA_TI_THREADS / 64 - 1) part[128] = t;      // grand total
-    }
-    __syncthreads();
-    unsigned run = part[64 + (tid >> 6)] + inc - sum;
-    for (int v = v0; v < v1; ++v) {
-        const unsigned n = cnt[v];
-        cnt[v] = run;
-        seg_start[v] = (int)run;
-        if (n > NVQA_ES_SHORT) { // (which slot a token gets does not matter)
-            const unsigned slot = atomicAdd(nlong, 1u);
-            long_tok[slot] = v;
-            done[slot] = 0;
-        }
-        run += n;
-    }
-    const unsigned total = part[128];
-    if (tid == NVQA_TI_THREADS - 1) seg_start[VT] = (int)total;
-    __syncthreads();
-    if (tid == 0) *nlong_out = (int)*nlong;
-#pragma unroll
-    for (int i = 0; i < NVQA_TI_NPT; ++i)
-        if (w[i] >= 0) tmp[atomicAdd(&cnt[w[i]], 1u)] = ((unsigned)w[i] << 16) | (unsigned)(tid + i * NVQA_TI_THREADS);
-    __syncthreads();
-    // order inside a group: rank of each position among its group (groups are short, or a few long ones); cnt[v] is now
-    // the END of token v's group, so its start is the end of the group before it
-    for (unsigned p = tid; p < total; p += NVQA_TI_THREADS) {
-        const unsigned x = tmp[p], v = x >> 16;
-        const unsigned s = v ? cnt[v - 1] : 0u, e = cnt[v];
-        unsigned rank = 0;
-        for (unsigned q = s; q < e; ++q) rank += tmp[q] < x ? 1u : 0u;
-        perm[s + rank] = (uint16_t)(x & 0xffffu);
-    }
+    tok_index_body<NVQA_TI_THREADS>(ti_smem, t);
 }
 
 // rows of positions [lo, hi) of perm, summed in that order: 8 rows in flight, both column passes of a lane together

@@ -130,7 +130,7 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
                                                   float *smem)
 {
     typedef PersistGeom<G0, G1, MT, BF> GE;
-    constexpr int GPC = GE::GPC, KG = 64 / GPC;
+    constexpr int GPC = GE::GPC;
     static_assert(G1 % GPC == 0, "R must be a multiple of 64");
     // D: chunks between a chunk's loads and its multiplication (= staging-register sets).  f32: a chunk is 1.7 us of MFMAs,
     // two of them cover the L2 round trip.  bf16: 0.1 us -- the step is a chain of load latencies, 16 / D of them, so as
@@ -353,7 +353,6 @@ __device__ __forceinline__ void persist_fwd_layer(const PersistFwdArgs &a, const
     // latency with one fragment set; the two row tiles of a pair alternate so that an accumulator is reused every
     // second MFMA (40-cycle dependent latency, 32-cycle issue).
     auto mfma_group = [&](auto q_tag, auto g_tag, const float *cur, const float *nxt, auto &&hook) {
-        constexpr bool live = true;
         constexpr int q = decltype(q_tag)::value, g = decltype(g_tag)::value;
         constexpr bool s1 = q >= NC0;
         constexpr int c = s1 ? q - NC0 : q;

@@ -29,6 +29,7 @@
 // the A operand comes from the bf16 image of dG that the cell backward writes next to the f32 one; the LDS image of a
 // chunk has the f32 layout byte for byte (a 16-byte piece is a lane's A fragment: 4 f32 or 8 bf16).
 #pragma once
+#include "tok_index.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -53,6 +54,8 @@ struct PersistBwd2Args {
     int dbg;                 // measurement only (NVQA_PB_DBG): 1 no flag waits, 2 no cell math / stores, 8 A loads without memory traffic
     int B, R, L, TS, RB, NU; // NU = R / (16 NTN) unit tiles
     Drop dr;
+    const TokIndexArgs *tok; // != NULL: the first workgroup without a role builds the embedding gradient's token index (tok_index.h);
+                             // a pointer to a device copy of the job (the context's own buffers: written once)
 };
 
 // MTA / MTB: row tiles of 16 rows in half 0 / half 1 (MTA >= MTB); NTN column tiles of 16 units; GPC K groups per gate
@@ -74,6 +77,13 @@ template <int MTA, int MTB, int NTN, int GPC> struct PersistBwd2Geom {
     static constexpr int SROW = UNITS + 4;
     static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWSH * SROW + BSUM_FLOATS + DC_FLOATS) * 4;
 };
+
+// the token-index job of a workgroup without a role (inlined: as a real call it measured 0.01 ms slower per launch -- the
+// callee's register needs then shape the whole kernel's allocation)
+__device__ __forceinline__ void pb2_tok_index_job(unsigned *smem, const TokIndexArgs *t)
+{
+    tok_index_body<NVQA_PF_THREADS>(smem, *t);
+}
 
 template <int N> __device__ __forceinline__ void pb_wait_vmcnt()
 {
@@ -112,7 +122,12 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     const int ngroups = (2 * L - 1) * RBn, gpx = 32 / a.NU > 0 ? 32 / a.NU : 1;
     const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int gslot = xcd * gpx + slot / a.NU, ut = slot % a.NU;
-    if (slot / a.NU >= gpx || gslot >= ngroups) return;
+    if (slot / a.NU >= gpx || gslot >= ngroups) {
+        // a slot without a role.  One of them carries the step's token-index job (needed behind this launch only; the host
+        // made the dynamic LDS large enough): off the critical path, no launch of its own
+        if (a.tok && slot / a.NU < gpx && gslot == ngroups && ut == 0) pb2_tok_index_job(reinterpret_cast<unsigned *>(pb2_smem), a.tok);
+        return;
+    }
     int role, rb;
     if (L == 1) { role = 0; rb = gslot; }
     else if (gslot < 2 * RBn) { role = (gslot & 1) ? L : 0; rb = gslot >> 1; }
@@ -166,7 +181,6 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     const unsigned lds_w = (unsigned)(prow * ROWW + 4 * ((pp & ~15) | ((pp & 15) ^ (prow & 15)))); // (rows prow + RPS j: same low 4 bits iff RPS = 16; else recomputed)
 
     pf_u32x4 stg[D][NLDM];
-    int mt_cur = MTA + MTB; // RAG: local row tiles with rows active at the step being LOADED / multiplied (set per half-step)
     // half-step k = 2 (TS-1-s) + h
     auto kstep = [&](int k) { return TS - 1 - (k >> 1); };
     // A slice of half-step k: REC: dG^l_{s+1}; UP: dG^{l+1}_s

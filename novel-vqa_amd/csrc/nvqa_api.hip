@@ -389,6 +389,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->act_b16) (void)hipFree(c->act_b16);
     if (c->dg_b16) (void)hipFree(c->dg_b16);
     if (c->wi2h0_t16) (void)hipFree(c->wi2h0_t16);
+    if (c->tok_job_dev) (void)hipFree(c->tok_job_dev);
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
     if (c->pb_bias) (void)hipFree(c->pb_bias);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
@@ -736,7 +737,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
 static int lstm_backward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
-    const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
+    const int B = d.B, R = d.R, L = d.L, TS = c->TS;
     {
         int RB = 0;
         if (const int MT = persist_bwd_rows(c, &RB)) { c->img_bwd_valid = c->bf16; return lstm_backward_persist(c, dr, MT, RB); }
@@ -917,27 +918,48 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
 // token list is built on a side stream as soon as the forward pass has written ptok, under the LSTM unroll.
 static bool emb_index_ok(const nvqa_ctx *c, int VT, int NP)
 {
-    return c->tok_seg && NP <= NVQA_TI_NPT * NVQA_TI_THREADS && VT <= 65535 && tok_index_lds(VT, NP) <= 160 * 1024 && c->d.E <= 512;
+    return c->tok_seg && NP <= NVQA_TI_MAXNP && VT <= 65535 && tok_index_lds(VT, NP) <= 160 * 1024 && c->d.E <= 512;
 }
-// (Main stream.  Round 3 tried the side stream behind the forward kernel, under the head's GEMMs: SLOWER -- 3.175 vs 3.144 ms
-// per step, 1.412 vs 1.403 in bf16 arch2: the one-workgroup kernel with its 160 KB of LDS waits for a whole CU to drain and
-// then delays whatever needs that CU next, the persistent BPTT launch in the worst case.)
-static int emb_index_begin(nvqa_ctx *c, int VT, int NP)
+static TokIndexArgs tok_index_args(nvqa_ctx *c, int VT, int NP)
 {
-    if (!emb_index_ok(c, VT, NP)) return 0;
+    return TokIndexArgs{c->ptok, NP, VT, c->seg_start, c->perm, c->pslot, c->seg_done, c->pslot + (NP / NVQA_ES_SHORT + 2)};
+}
+static int tok_index_launch(nvqa_ctx *c, int VT, int NP)
+{
     static bool attr = false;
     if (!attr) { NVQA_HIP(hipFuncSetAttribute((const void *)k_tok_index, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     ProfScope ps(c, PF_ASSEMBLE, 0, 0);
-    hipLaunchKernelGGL(k_tok_index, dim3(1), dim3(NVQA_TI_THREADS), tok_index_lds(VT, NP), c->s, c->ptok, NP, VT, c->seg_start, c->perm,
-                       c->pslot, c->seg_done, c->pslot + (NP / NVQA_ES_SHORT + 2));
+    hipLaunchKernelGGL(k_tok_index, dim3(1), dim3(NVQA_TI_THREADS), tok_index_lds(VT, NP), c->s, tok_index_args(c, VT, NP));
     NVQA_HIP(hipGetLastError());
     return 0;
+}
+// The index of this step's packed token list.  Where the step's BPTT is the persistent launch, the job rides in one of that
+// launch's idle workgroups (tok_index.h; c->tok_job is consumed by lstm_backward_persist; NVQA_TOK_IN_BPTT=0: own kernel);
+// otherwise it is a one-workgroup kernel of its own on the main stream.  (Round 3 also tried that kernel on the side stream
+// behind the forward kernel, under the head's GEMMs: SLOWER -- 3.175 vs 3.144 ms per step: with its 160 KB of LDS it waits
+// for a whole CU to drain and then delays whatever needs that CU next, the persistent BPTT launch in the worst case.)
+static int emb_index_begin(nvqa_ctx *c, int VT, int NP)
+{
+    c->tok_job_pending = false;
+    if (!emb_index_ok(c, VT, NP)) return 0;
+    static const bool ride = [] { const char *e = getenv("NVQA_TOK_IN_BPTT"); return !(e && e[0] == '0'); }();
+    int RB = 0;
+    if (ride && persist_bwd_rows(c, &RB)) {
+        c->tok_job = tok_index_args(c, VT, NP);
+        c->tok_job_pending = true;
+        return 0;
+    }
+    return tok_index_launch(c, VT, NP);
 }
 // dWeT [VT][E] = sum over the packed positions of each token; plain = 1: nn.LookupTable (arch2), 0: arch1's Tanh + Dropout
 static int emb_backward(nvqa_ctx *c, int VT, int NP, int T, const float *dX, const Drop &dr, float *dWeT, int plain)
 {
     const nvqa_dims &d = c->d;
     const int E = d.E, B = d.B;
+    if (c->tok_job_pending) { // no persistent BPTT launch took the job after all (fallback path): build the index now
+        c->tok_job_pending = false;
+        NVQA_TRY(tok_index_launch(c, VT, NP));
+    }
     ProfScope ps(c, PF_EMB_BWD, 0, (2.0 * NP * E + (double)VT * E) * 4);
     if (emb_index_ok(c, VT, NP)) {
         const int slots = NP / NVQA_ES_SHORT + 2; // c->pslot: [slots] tokens of the long segments, then their number

@@ -3,6 +3,7 @@
 // form is faster in both precisions (f32 1.10 -> 0.91 ms, bf16 0.55 -> 0.45 ms) and one BPTT route beside the per-level
 // fallback is enough.
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 #include "lstm_persist_bwd2.h"
@@ -37,7 +38,8 @@ int persist_bwd_rows(const nvqa_ctx *c, int *RB)
 template <class K> static int check_resident(nvqa_ctx *c, K kernel, size_t lds, int grid, int *resident)
 {
     if (*resident < 0) {
-        NVQA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // (the whole CU's LDS: a launch that carries the token-index job asks for more than the kernel's own layout)
+        NVQA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int nb = 0;
         NVQA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NVQA_PF_THREADS, lds));
         *resident = nb;
@@ -52,7 +54,8 @@ template <class K> static int check_resident(nvqa_ctx *c, K kernel, size_t lds, 
 template <int GKT, int MTA, int MTB, int NTN, int GPC, bool BF, bool RAG>
 static int launch_persist_bwd2(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
 {
-    const size_t lds = PersistBwd2Geom<MTA, MTB, NTN, GPC>::LDS_BYTES;
+    size_t lds = PersistBwd2Geom<MTA, MTB, NTN, GPC>::LDS_BYTES;
+    if (a.tok) lds = std::max(lds, tok_index_lds(c->tok_job.VT, c->tok_job.NP));
     static int resident = -1;
     NVQA_TRY(check_resident(c, k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>, lds, grid, &resident));
     hipLaunchKernelGGL((k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
@@ -96,6 +99,17 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = err;
         a.bias_part = c->pb_bias;
         a.ts = c->pf_ts + 1024;
+        // the token-index job of this step rides in a workgroup without a role, if the grid has one
+        if (c->tok_job_pending && (2 * L - 1) * RB < 8 * std::max(1, 32 / NU) && tok_index_lds(c->tok_job.VT, c->tok_job.NP) <= 160 * 1024) {
+            if (!c->tok_job_dev) NVQA_HIP(hipMalloc((void **)&c->tok_job_dev, sizeof(TokIndexArgs)));
+            if (memcmp(&c->tok_job_dev_host, &c->tok_job, sizeof(TokIndexArgs)) != 0) { // (the job's arguments are the context's own buffers: once)
+                NVQA_HIP(hipMemcpyAsync(c->tok_job_dev, &c->tok_job, sizeof(TokIndexArgs), hipMemcpyHostToDevice, c->s));
+                NVQA_HIP(hipStreamSynchronize(c->s));
+                c->tok_job_dev_host = c->tok_job;
+            }
+            a.tok = c->tok_job_dev;
+            c->tok_job_pending = false;
+        }
 #define NVQA_PB2_GO(GKT, MTA, MTB, NTN, GPC, BFv)                                                                   \
     do {                                                                                                             \
         if (rag) NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, true>(c, a, grid)));                    \
