@@ -166,9 +166,12 @@ template <int BK> __device__ __forceinline__ int swz_chunk(int row, int chunk)
     else return chunk ^ ((row >> 1) & 7);
 }
 
-template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG>
+// EXT: the LDS tile buffers are the caller's (smem_ext, SMEM floats as computed below) instead of a static array of this
+// function -- for a caller that runs tiles of a product inside ANOTHER kernel (lstm_persist_bwd2.h: the workgroups without a
+// role multiply head weight gradients under the BPTT) and must not add static LDS to it.
+template <class C, int AMODE, int BMODE, bool GATES, class Epi, int SEG, bool EXT = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi, const int bx, const int by,
-                                              const int bz)
+                                              const int bz, float *smem_ext = nullptr)
 {
     constexpr int MF = C::MF, BM = C::BM, BN = C::BN, BK = C::BK, WM = C::WM, WN = C::WN, WK = C::WK,
                   PF = C::PF;
@@ -208,7 +211,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs &g, const Epi &epi,
     constexpr int NBUF = DMA ? 2 : PF;
     constexpr int SMEM = (NBUF * BUF > RED ? NBUF * BUF : RED);
 
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float *smem;
+    if constexpr (EXT) {
+        smem = smem_ext;
+    } else {
+        __shared__ __attribute__((aligned(16))) float smem_static[SMEM];
+        smem = smem_static;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "lstm_persist.h"
+#include "ride_jobs.h"
 
 namespace nvqa {
 
@@ -54,8 +55,8 @@ struct PersistBwd2Args {
     int dbg;                 // measurement only (NVQA_PB_DBG): 1 no flag waits, 2 no cell math / stores, 8 A loads without memory traffic
     int B, R, L, TS, RB, NU; // NU = R / (16 NTN) unit tiles
     Drop dr;
-    const TokIndexArgs *tok; // != NULL: the first workgroup without a role builds the embedding gradient's token index (tok_index.h);
-                             // a pointer to a device copy of the job (the context's own buffers: written once)
+    const RideJobs *jobs;    // != NULL: work for the workgroups without a role (ride_jobs.h): a device copy of the job list (its
+                             // arguments are the context's own buffers: written once)
 };
 
 // MTA / MTB: row tiles of 16 rows in half 0 / half 1 (MTA >= MTB); NTN column tiles of 16 units; GPC K groups per gate
@@ -77,13 +78,6 @@ template <int MTA, int MTB, int NTN, int GPC> struct PersistBwd2Geom {
     static constexpr int SROW = UNITS + 4;
     static constexpr size_t LDS_BYTES = (size_t)(NST * STAGE + 4 * ROWSH * SROW + BSUM_FLOATS + DC_FLOATS) * 4;
 };
-
-// the token-index job of a workgroup without a role (inlined: as a real call it measured 0.01 ms slower per launch -- the
-// callee's register needs then shape the whole kernel's allocation)
-__device__ __forceinline__ void pb2_tok_index_job(unsigned *smem, const TokIndexArgs *t)
-{
-    tok_index_body<NVQA_PF_THREADS>(smem, *t);
-}
 
 template <int N> __device__ __forceinline__ void pb_wait_vmcnt()
 {
@@ -123,9 +117,11 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int gslot = xcd * gpx + slot / a.NU, ut = slot % a.NU;
     if (slot / a.NU >= gpx || gslot >= ngroups) {
-        // a slot without a role.  One of them carries the step's token-index job (needed behind this launch only; the host
-        // made the dynamic LDS large enough): off the critical path, no launch of its own
-        if (a.tok && slot / a.NU < gpx && gslot == ngroups && ut == 0) pb2_tok_index_job(reinterpret_cast<unsigned *>(pb2_smem), a.tok);
+        // a slot without a role.  The workgroups of the slot groups behind the last role (f32, L = 2: one group of 16; bf16:
+        // 8 groups of 8) share the step's ride-along jobs (ride_jobs.h; the host made the dynamic LDS large enough): off the
+        // critical path, no launch of their own.  (inlined: as a real call it measured 0.01 ms slower per launch -- the
+        // callee's register needs then shape the whole kernel's allocation)
+        if (a.jobs && slot / a.NU < gpx) ride_jobs_run<BF>(a.jobs, (gslot - ngroups) * a.NU + ut, (8 * gpx - ngroups) * a.NU, pb2_smem);
         return;
     }
     int role, rb;

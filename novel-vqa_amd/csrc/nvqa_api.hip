@@ -314,6 +314,8 @@ static int create_impl(nvqa_ctx *c)
     {   // persistent forward LSTM (lstm_persist.h) where the shape is eligible; NVQA_PERSIST=0: one launch per wavefront level
         const char *ep = getenv("NVQA_PERSIST");
         c->persist_on = !(ep && ep[0] == '0');
+        { const char *e = getenv("NVQA_RIDE_GEMM"); c->ride_gemm_on = !(e && e[0] == '0'); }   // A/B switches of the ride-along jobs,
+        { const char *e = getenv("NVQA_TOK_IN_BPTT"); c->tok_in_bptt_on = !(e && e[0] == '0'); } // read here like the other switches
         hipDeviceProp_t prop;
         NVQA_HIP(hipGetDeviceProperties(&prop, c->device));
         c->num_cus = prop.multiProcessorCount;
@@ -389,7 +391,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->act_b16) (void)hipFree(c->act_b16);
     if (c->dg_b16) (void)hipFree(c->dg_b16);
     if (c->wi2h0_t16) (void)hipFree(c->wi2h0_t16);
-    if (c->tok_job_dev) (void)hipFree(c->tok_job_dev);
+    if (c->ride_dev) (void)hipFree(c->ride_dev);
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
     if (c->pb_bias) (void)hipFree(c->pb_bias);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
@@ -934,7 +936,7 @@ static int tok_index_launch(nvqa_ctx *c, int VT, int NP)
     return 0;
 }
 // The index of this step's packed token list.  Where the step's BPTT is the persistent launch, the job rides in one of that
-// launch's idle workgroups (tok_index.h; c->tok_job is consumed by lstm_backward_persist; NVQA_TOK_IN_BPTT=0: own kernel);
+// launch's idle workgroups (ride_jobs.h; c->ride is consumed by lstm_backward_persist; NVQA_TOK_IN_BPTT=0: own kernel);
 // otherwise it is a one-workgroup kernel of its own on the main stream.  (Round 3 also tried that kernel on the side stream
 // behind the forward kernel, under the head's GEMMs: SLOWER -- 3.175 vs 3.144 ms per step: with its 160 KB of LDS it waits
 // for a whole CU to drain and then delays whatever needs that CU next, the persistent BPTT launch in the worst case.)
@@ -942,10 +944,9 @@ static int emb_index_begin(nvqa_ctx *c, int VT, int NP)
 {
     c->tok_job_pending = false;
     if (!emb_index_ok(c, VT, NP)) return 0;
-    static const bool ride = [] { const char *e = getenv("NVQA_TOK_IN_BPTT"); return !(e && e[0] == '0'); }();
     int RB = 0;
-    if (ride && persist_bwd_rows(c, &RB)) {
-        c->tok_job = tok_index_args(c, VT, NP);
+    if (c->tok_in_bptt_on && persist_bwd_rows(c, &RB)) {
+        c->ride.tok = tok_index_args(c, VT, NP);
         c->tok_job_pending = true;
         return 0;
     }
@@ -1049,6 +1050,34 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     return 0;
 }
 
+// Head weight gradients that only the optimiser needs: in single-GPU runs they ride in the idle workgroups of the persistent
+// BPTT launch (ride_jobs.h) instead of taking their time on the critical path in front of it.  (With a communicator the
+// segment they belong to is exchanged before the BPTT, and the idle slots belong to the collective's kernels: computed in
+// place then.)  NVQA_RIDE_GEMM=0: always in place.
+static bool ride_begin(nvqa_ctx *c)
+{
+    int rb = 0;
+    c->ride.ngemm = 0;
+    c->ride_gemm_pending = false;
+    return c->ride_gemm_on && !c->comm && persist_bwd_rows(c, &rb) != 0;
+}
+static void ride_add(nvqa_ctx *c, const GemmArgs &g, const EpiStore &e)
+{
+    RideGemm &r = c->ride.gm[c->ride.ngemm++];
+    r.g = g; r.e = e;
+    r.tx = (g.N + CfgRide::BN - 1) / CfgRide::BN; r.ty = (g.M + CfgRide::BM - 1) / CfgRide::BM;
+    c->ride_gemm_pending = true;
+}
+// behind lstm_backward: products the persistent launch did not take (fallback path, no free slot group) are computed now
+static int ride_flush(nvqa_ctx *c)
+{
+    if (!c->ride_gemm_pending) return 0;
+    c->ride_gemm_pending = false;
+    ProfScope ps(c, PF_GEMM_HEAD_BWD, 0, 0);
+    for (int i = 0; i < c->ride.ngemm; ++i) NVQA_TRY((gemm_med<A_MC, B_NC>(c, c->ride.gm[i].g, c->ride.gm[i].e)));
+    return 0;
+}
+
 static int arch1_backward(nvqa_ctx *c, const Drop &dr)
 {
     const nvqa_dims &d = c->d;
@@ -1061,11 +1090,17 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
                      (2.0 * A * C + 2.0 * C * Q + 2.0 * C * I) * 4);
         // classifier: dW_o = dscores^T zd ; d(zd) = dscores W_o -> Dropout', CMul', Tanh'
         const int ZW = c->fusion_askip == 2 ? 2 * C : C;
-        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0})));
+        // dW_o and dW_q are needed only by the optimiser: in single-GPU runs they ride in the idle workgroups of the persistent
+        // BPTT launch (ride_jobs.h) instead of taking 40 us of the critical path here.  (With a communicator the multimodal
+        // segment is exchanged before the BPTT, so they are computed here.)  NVQA_RIDE_GEMM=0: always here.
+        const bool ride = ride_begin(c);
+        if (ride) ride_add(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0});
+        else NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0})));
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, ZW, B, ZW, A),
                                        EpiHeadBwd{c->dqc, c->dic, c->qc, c->ic, C, dr, c->fusion_askip})));
         // fusion: dW_q = dqc^T qd ; dW_v = dic^T vd ; d(qd) = dqc W_q (no gradient to the image)
-        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dqc, C, c->qd, Q, C, Q, B), EpiStore{G + c->lo.w_q, Q, 0})));
+        if (ride) ride_add(c, mkargs(c->dqc, C, c->qd, Q, C, Q, B), EpiStore{G + c->lo.w_q, Q, 0});
+        else NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dqc, C, c->qd, Q, C, Q, B), EpiStore{G + c->lo.w_q, Q, 0})));
         NVQA_TRY((gemm_big<A_MC, B_NC>(c, mkargs(c->dic, C, c->vd, I, C, I, B), EpiStore{G + c->lo.w_v, I, 0})));
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dqc, C, c->P + c->lo.w_q, Q, B, Q, C),
                                        EpiResort{c->dCT, c->dHT, c->sort_inv, B, R, Q, dr})));
@@ -1089,6 +1124,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
     float *dX0 = c->dX0;
     NVQA_TRY(lstm_backward(c, dr));
+    NVQA_TRY(ride_flush(c));
     // embedding gradient first, so that its 11.8 MB all-reduce and those of the upper LSTM layers travel
     // under the weight-gradient GEMMs; only layer 0's slice (5.8 MB) is exchanged after the last kernel
     NVQA_TRY(lstm_dx0(c, dX0));
@@ -1146,6 +1182,7 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
 
 static int arch2_backward(nvqa_ctx *c, const Drop &dr)
 {
+    const bool ride = ride_begin(c);
     const nvqa_dims &d = c->d;
     const int B = d.B, R = d.R, L = d.L, E = d.E, I = d.I, A = d.A, V = d.V, TS = c->TS, TB = TS * B;
     float *G = c->G;
@@ -1154,7 +1191,8 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_HIP(hipMemsetAsync(c->dHT, 0, (size_t)L * B * R * 4, c->s));
     {
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 4.0 * B * A * R, (2.0 * A * R + 2.0 * B * A) * 4);
-        NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->qd, R, A, R, B), EpiStore{G + c->lo.w_o, R, 0})));
+        if (ride) ride_add(c, mkargs(c->dscores, A, c->qd, R, A, R, B), EpiStore{G + c->lo.w_o, R, 0});
+        else NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->qd, R, A, R, B), EpiStore{G + c->lo.w_o, R, 0})));
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, R, B, R, A),
                                        EpiHead2{c->dHT + (size_t)(L - 1) * B * R, R, dr})));
     }
@@ -1165,6 +1203,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
     NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr));
+    NVQA_TRY(ride_flush(c));
     NVQA_TRY(lstm_dx0(c, c->dX0));
     {   // cnn_projection:backward (002_train_baseline.lua:322): dW_p = dx_1^T fv_im, db_p = colsum(dx_1)
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 2.0 * B * E * I, ((double)B * (E + I) + (double)E * I) * 4);

@@ -1,7 +1,7 @@
 // nvqa_ctx.h -- library-owned state behind the opaque nvqa_ctx of include/nvqa.h.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "tok_index.h"
+#include "ride_jobs.h"
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -77,9 +77,11 @@ struct nvqa_ctx {
     hipStream_t sx = nullptr;                    // side stream: the token-segment index of the embedding gradient, under the forward pass
     hipEvent_t evTok = nullptr, evIdx = nullptr; // ptok written / index ready
     bool tok_seg = true;                         // NVQA_EMB_SEG=0: the scanning kernel (k_emb_bwd) instead
-    TokIndexArgs tok_job = {};                   // this step's token-index job, waiting for the persistent BPTT launch to carry it
-    bool tok_job_pending = false;
-    TokIndexArgs *tok_job_dev = nullptr, tok_job_dev_host = {}; // device copy of the job (and what it holds)
+    // ride-along jobs of this step (ride_jobs.h), waiting for the persistent BPTT launch to carry them in its idle workgroups
+    nvqa::RideJobs ride = {}, ride_dev_host = {}; // the list, and what the device copy holds
+    nvqa::RideJobs *ride_dev = nullptr;
+    bool tok_job_pending = false, ride_gemm_pending = false;
+    bool ride_gemm_on = true, tok_in_bptt_on = true; // NVQA_RIDE_GEMM / NVQA_TOK_IN_BPTT (read by nvqa_create)
     int32_t *seg_start = nullptr, *pslot = nullptr;
     uint16_t *perm = nullptr;
     unsigned *seg_done = nullptr;

@@ -55,7 +55,7 @@ template <int GKT, int MTA, int MTB, int NTN, int GPC, bool BF, bool RAG>
 static int launch_persist_bwd2(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
 {
     size_t lds = PersistBwd2Geom<MTA, MTB, NTN, GPC>::LDS_BYTES;
-    if (a.tok) lds = std::max(lds, tok_index_lds(c->tok_job.VT, c->tok_job.NP));
+    if (a.jobs && c->ride.has_tok) lds = std::max(lds, tok_index_lds(c->ride.tok.VT, c->ride.tok.NP));
     static int resident = -1;
     NVQA_TRY(check_resident(c, k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>, lds, grid, &resident));
     hipLaunchKernelGGL((k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
@@ -99,16 +99,19 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = err;
         a.bias_part = c->pb_bias;
         a.ts = c->pf_ts + 1024;
-        // the token-index job of this step rides in a workgroup without a role, if the grid has one
-        if (c->tok_job_pending && (2 * L - 1) * RB < 8 * std::max(1, 32 / NU) && tok_index_lds(c->tok_job.VT, c->tok_job.NP) <= 160 * 1024) {
-            if (!c->tok_job_dev) NVQA_HIP(hipMalloc((void **)&c->tok_job_dev, sizeof(TokIndexArgs)));
-            if (memcmp(&c->tok_job_dev_host, &c->tok_job, sizeof(TokIndexArgs)) != 0) { // (the job's arguments are the context's own buffers: once)
-                NVQA_HIP(hipMemcpyAsync(c->tok_job_dev, &c->tok_job, sizeof(TokIndexArgs), hipMemcpyHostToDevice, c->s));
+        // this step's ride-along jobs (ride_jobs.h) go to the workgroups without a role, if the grid has a free slot group
+        if ((c->tok_job_pending || c->ride_gemm_pending) && (2 * L - 1) * RB < 8 * std::max(1, 32 / NU) &&
+            (!c->tok_job_pending || tok_index_lds(c->ride.tok.VT, c->ride.tok.NP) <= 160 * 1024)) {
+            c->ride.has_tok = c->tok_job_pending ? 1 : 0;
+            if (!c->ride_gemm_pending) c->ride.ngemm = 0;
+            if (!c->ride_dev) NVQA_HIP(hipMalloc((void **)&c->ride_dev, sizeof(RideJobs)));
+            if (memcmp(&c->ride_dev_host, &c->ride, sizeof(RideJobs)) != 0) { // (the same list every step: uploaded once)
+                NVQA_HIP(hipMemcpyAsync(c->ride_dev, &c->ride, sizeof(RideJobs), hipMemcpyHostToDevice, c->s));
                 NVQA_HIP(hipStreamSynchronize(c->s));
-                c->tok_job_dev_host = c->tok_job;
+                memcpy(&c->ride_dev_host, &c->ride, sizeof(RideJobs));
             }
-            a.tok = c->tok_job_dev;
-            c->tok_job_pending = false;
+            a.jobs = c->ride_dev;
+            c->tok_job_pending = c->ride_gemm_pending = false;
         }
 #define NVQA_PB2_GO(GKT, MTA, MTB, NTN, GPC, BFv)                                                                   \
     do {                                                                                                             \

@@ -308,6 +308,42 @@ def test_persistent_bptt(pkg, orc, name):
     ctx.close()
 
 
+def test_ride_along_jobs(pkg, orc):
+    """Work that rides in the idle workgroups of the persistent BPTT launch (csrc/ride_jobs.h): the token index of the embedding
+    gradient and the head weight gradients dW_o, dW_q (arch1) / dW_o (arch2).  Same K order per output as the kernels they
+    replace, so the gradients must be BIT-IDENTICAL to a context with the jobs in their own launches (NVQA_RIDE_GEMM=0,
+    NVQA_TOK_IN_BPTT=0), in f32 and in bf16 mode; against the oracle the default path is covered by every other test."""
+    for kw, bf16 in ((FULL1, False), (FULL1, True), (PERSIST_CASES["arch2_L2"][0], False)):
+        d = orc.make_dims(**kw)
+        params = orc.synth_params(d)
+        tok, lens, img, lab = orc.synth_batch(d, seed=5, full_length=d.arch == 2, min_len=3)
+        lens = lens if d.arch == 1 else None
+        got = []
+        for env in ({}, {"NVQA_RIDE_GEMM": "0", "NVQA_TOK_IN_BPTT": "0"}):
+            ctx = _ctx(pkg, d, env)
+            ctx.set_params(params)
+            if bf16:
+                ctx.set_precision(1)
+            for it in range(2):  # the second step reuses the device copy of the job list
+                loss = ctx.step(tok, lens, img, lab, gdrop(pkg, orc.Dropout(1, 0.5, 123, 40 + it)))
+            got.append((loss, ctx.get_grads()))
+            ctx.close()
+        assert got[0][0] == got[1][0]
+        assert np.array_equal(got[0][1], got[1][1]), float(np.abs(got[0][1] - got[1][1]).max())
+
+
+def test_ride_along_jobs_without_a_free_slot(pkg, orc):
+    """L = 1, B = 1024: 16 row blocks x 16 unit tiles fill all 256 slots of the BPTT grid -- no workgroup without a role.  The
+    jobs must then run in their own launches behind the BPTT (ride_flush / emb_backward's fallback): against the oracle."""
+    d = orc.make_dims(arch=1, B=1024, T=4, V=300, E=200, R=512, L=1, I=64, C=64, A=40)
+    params = orc.synth_params(d)
+    ctx = _ctx(pkg, d, {})
+    ctx.set_params(params)
+    b = orc.synth_batch(d, seed=9, full_length=False, min_len=2)
+    _check_step(pkg, orc, d, ctx, params, b, orc.Dropout(1, 0.5, 123, 50), TOL_GRAD, "ride_no_free_slot")
+    ctx.close()
+
+
 def test_persistent_kernel_timeout_is_reported_and_survived(pkg, orc, monkeypatch):
     """The give-up path of the persistent kernels: with NVQA_PF_SPIN = 1 every cross-workgroup wait gives up at
     its second poll, so a full-size step MUST time out.  Required: the launch drains (no hang), the failure survives an
