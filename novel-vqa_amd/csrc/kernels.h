@@ -4,7 +4,7 @@
 // where the row width allows, no atomics on floats (results are bit-reproducible).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "tok_index.h"
+#include "ride_jobs.h"
 #include "../../include/nvqa_layout.h"
 #include "epilogues.h"
 #include "gemm_f32.h"
@@ -316,35 +316,12 @@ __global__ void k_colsum_final(const float *part, int S, int N, float *out, floa
 
 // Several SHORT column sums (M = B rows: the head's bias gradients) in one launch and one stage: a block owns
 // 64 columns of one problem and walks all its rows (4 row lanes x 4 independent chains), fixed order.
-struct ColsumBatch {
-    const float *X[4];
-    float *out[4];
-    int M[4], N[4], ld[4];
-    int first_block[5]; // block range of problem p: [first_block[p], first_block[p+1])
-};
+// (struct ColsumBatch and the block body colsum_batch_block live in ride_jobs.h: the same body also runs inside the idle
+// workgroups of the persistent BPTT launch.)
 __global__ void k_colsum_batch(ColsumBatch a)
 {
     __shared__ float sm[4][64];
-    int p = 0;
-    while (p < 3 && (int)blockIdx.x >= a.first_block[p + 1]) ++p;
-    const float *X = a.X[p];
-    const int M = a.M[p], N = a.N[p], ld = a.ld[p];
-    const int n = (blockIdx.x - a.first_block[p]) * 64 + (threadIdx.x & 63);
-    const int w = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (n < N) {
-        int m = w;
-        for (; m + 12 < M; m += 16) {
-            s0 += X[(size_t)m * ld + n];
-            s1 += X[(size_t)(m + 4) * ld + n];
-            s2 += X[(size_t)(m + 8) * ld + n];
-            s3 += X[(size_t)(m + 12) * ld + n];
-        }
-        for (; m < M; m += 4) s0 += X[(size_t)m * ld + n];
-    }
-    sm[w][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (w == 0 && n < N) a.out[p][n] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    colsum_batch_block(a, blockIdx.x, &sm[0][0]);
 }
 
 // sum of split-K slabs (fixed order) with optional accumulate into C

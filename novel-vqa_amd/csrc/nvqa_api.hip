@@ -1058,6 +1058,7 @@ static bool ride_begin(nvqa_ctx *c)
 {
     int rb = 0;
     c->ride.ngemm = 0;
+    c->ride.has_colsum = 0;
     c->ride_gemm_pending = false;
     return c->ride_gemm_on && !c->comm && persist_bwd_rows(c, &rb) != 0;
 }
@@ -1075,6 +1076,10 @@ static int ride_flush(nvqa_ctx *c)
     c->ride_gemm_pending = false;
     ProfScope ps(c, PF_GEMM_HEAD_BWD, 0, 0);
     for (int i = 0; i < c->ride.ngemm; ++i) NVQA_TRY((gemm_med<A_MC, B_NC>(c, c->ride.gm[i].g, c->ride.gm[i].e)));
+    if (c->ride.has_colsum) {
+        hipLaunchKernelGGL(k_colsum_batch, dim3(c->ride.cs.first_block[4]), dim3(256), 0, c->s, c->ride.cs);
+        NVQA_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1084,6 +1089,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     const int B = d.B, T = d.T, R = d.R, L = d.L, E = d.E, I = d.I, C = d.C, A = d.A, Q = 2 * R * L;
     const int TB = T * B, V = d.V;
     float *G = c->G;
+    const bool ride = ride_begin(c); // (ride_jobs.h)
     {
         ProfScope ps(c, PF_GEMM_HEAD_BWD,
                      2.0 * B * (2.0 * A * C + 2.0 * C * Q + (double)C * I),
@@ -1093,7 +1099,6 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
         // dW_o and dW_q are needed only by the optimiser: in single-GPU runs they ride in the idle workgroups of the persistent
         // BPTT launch (ride_jobs.h) instead of taking 40 us of the critical path here.  (With a communicator the multimodal
         // segment is exchanged before the BPTT, so they are computed here.)  NVQA_RIDE_GEMM=0: always here.
-        const bool ride = ride_begin(c);
         if (ride) ride_add(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0});
         else NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0})));
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, ZW, B, ZW, A),
@@ -1118,8 +1123,14 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
             blocks += (Ns[i] + 63) / 64;
         }
         cb.first_block[3] = cb.first_block[4] = blocks;
-        hipLaunchKernelGGL(k_colsum_batch, dim3(blocks), dim3(256), 0, c->s, cb);
-        NVQA_HIP(hipGetLastError());
+        if (ride) { // with the head weight gradients above: under the BPTT (ride_jobs.h)
+            c->ride.cs = cb;
+            c->ride.has_colsum = 1;
+            c->ride_gemm_pending = true;
+        } else {
+            hipLaunchKernelGGL(k_colsum_batch, dim3(blocks), dim3(256), 0, c->s, cb);
+            NVQA_HIP(hipGetLastError());
+        }
     }
     NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
     float *dX0 = c->dX0;

@@ -103,7 +103,22 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         if ((c->tok_job_pending || c->ride_gemm_pending) && (2 * L - 1) * RB < 8 * std::max(1, 32 / NU) &&
             (!c->tok_job_pending || tok_index_lds(c->ride.tok.VT, c->ride.tok.NP) <= 160 * 1024)) {
             c->ride.has_tok = c->tok_job_pending ? 1 : 0;
-            if (!c->ride_gemm_pending) c->ride.ngemm = 0;
+            if (!c->ride_gemm_pending) c->ride.ngemm = c->ride.has_colsum = 0;
+            // The products must not lengthen the launch.  Calibration (f32, L = 2, B = 512, T = 26: a 0.90 ms launch, 16 riding
+            // workgroups): 3.2 GFLOP of 64 x 64 tiles (dW_o + dW_q) leave the launch at 0.90 ms, every further 1.07 GFLOP (256 rows
+            // of dW_v) lengthened it by 0.15 ms.  So the load is capped at 3.4 GFLOP per 0.90 ms of launch and 16 riders; a BPTT step
+            // takes ~34 us in f32 (L = 2; ~21 for L = 1) and ~17 us in bf16.  What does not fit is computed behind the launch
+            // (ride_flush).
+            bool keep_gemms = false;
+            if (c->ride.ngemm > 0) {
+                double gf = 0;
+                for (int i = 0; i < c->ride.ngemm; ++i) gf += 2e-9 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
+                const int n_idle = (8 * std::max(1, 32 / NU) - (2 * L - 1) * RB) * NU;
+                const double bptt_ms = 1e-3 * TS * (c->bf16 ? 17.0 : 34.0) * (L == 1 ? 0.62 : 1.0);
+                keep_gemms = gf > 3.4 * (bptt_ms / 0.90) * (n_idle / 16.0);
+            }
+            RideJobs kept = c->ride;
+            if (keep_gemms) c->ride.ngemm = 0;
             if (!c->ride_dev) NVQA_HIP(hipMalloc((void **)&c->ride_dev, sizeof(RideJobs)));
             if (memcmp(&c->ride_dev_host, &c->ride, sizeof(RideJobs)) != 0) { // (the same list every step: uploaded once)
                 NVQA_HIP(hipMemcpyAsync(c->ride_dev, &c->ride, sizeof(RideJobs), hipMemcpyHostToDevice, c->s));
@@ -112,6 +127,11 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
             }
             a.jobs = c->ride_dev;
             c->tok_job_pending = c->ride_gemm_pending = false;
+            if (keep_gemms) { // ride_flush computes them behind the launch (the column sums went along)
+                c->ride = kept;
+                c->ride.has_colsum = 0;
+                c->ride_gemm_pending = true;
+            }
         }
 #define NVQA_PB2_GO(GKT, MTA, MTB, NTN, GPC, BFv)                                                                   \
     do {                                                                                                             \
