@@ -1074,7 +1074,9 @@ static int ride_flush(nvqa_ctx *c)
 {
     if (!c->ride_gemm_pending) return 0;
     c->ride_gemm_pending = false;
-    ProfScope ps(c, PF_GEMM_HEAD_BWD, 0, 0);
+    double fl = 0;
+    for (int i = 0; i < c->ride.ngemm; ++i) fl += 2.0 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
+    ProfScope ps(c, PF_GEMM_HEAD_BWD, fl, 0);
     for (int i = 0; i < c->ride.ngemm; ++i) NVQA_TRY((gemm_med<A_MC, B_NC>(c, c->ride.gm[i].g, c->ride.gm[i].e)));
     if (c->ride.has_colsum) {
         hipLaunchKernelGGL(k_colsum_batch, dim3(c->ride.cs.first_block[4]), dim3(256), 0, c->s, c->ride.cs);
@@ -1091,8 +1093,9 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
     float *G = c->G;
     const bool ride = ride_begin(c); // (ride_jobs.h)
     {
+        // (the two products that ride under the BPTT are booked there, if the launch takes them)
         ProfScope ps(c, PF_GEMM_HEAD_BWD,
-                     2.0 * B * (2.0 * A * C + 2.0 * C * Q + (double)C * I),
+                     2.0 * B * ((ride ? 1.0 : 2.0) * A * C + (ride ? 1.0 : 2.0) * C * Q + (double)C * I),
                      (2.0 * A * C + 2.0 * C * Q + 2.0 * C * I) * 4);
         // classifier: dW_o = dscores^T zd ; d(zd) = dscores W_o -> Dropout', CMul', Tanh'
         const int ZW = c->fusion_askip == 2 ? 2 * C : C;

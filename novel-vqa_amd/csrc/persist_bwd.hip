@@ -80,7 +80,21 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     const int grid = 256; // 8 XCDs x 32 slots (the kernels map groups to XCDs); (2L-1) * RB * NU of them have work
     double flops = 0;
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * R * ((double)(TS - 1) + (l + 1 < L ? TS : 0));
-    ProfScope ps(c, PF_LSTM_BWD, flops, 0);
+    // Ride-along jobs (ride_jobs.h): do the idle workgroups exist, and do the weight-gradient products fit?  They must not
+    // lengthen the launch.  Calibration (f32, L = 2, B = 512, T = 26: a 0.90 ms launch, 16 riding workgroups): 3.2 GFLOP of
+    // 64 x 64 tiles (dW_o + dW_q) leave the launch at 0.90 ms, every further 1.07 GFLOP (256 rows of dW_v) lengthened it by
+    // 0.15 ms.  So the load is capped at 3.4 GFLOP per 0.90 ms of launch and 16 riders; a BPTT step takes ~34 us in f32 (L = 2;
+    // ~21 for L = 1) and ~17 us in bf16.  What does not fit is computed behind the launch (ride_flush).
+    const int n_idle = (8 * std::max(1, 32 / NU) - (2 * L - 1) * RB) * NU;
+    const bool take_jobs = (c->tok_job_pending || c->ride_gemm_pending) && n_idle > 0 &&
+                           (!c->tok_job_pending || tok_index_lds(c->ride.tok.VT, c->ride.tok.NP) <= 160 * 1024);
+    double ride_flops = 0;
+    if (take_jobs && c->ride_gemm_pending)
+        for (int i = 0; i < c->ride.ngemm; ++i) ride_flops += 2.0 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
+    const double bptt_ms = 1e-3 * TS * (c->bf16 ? 17.0 : 34.0) * (L == 1 ? 0.62 : 1.0);
+    const bool keep_gemms = ride_flops * 1e-9 > 3.4 * (bptt_ms / 0.90) * (n_idle / 16.0);
+    if (keep_gemms) ride_flops = 0;
+    ProfScope ps(c, PF_LSTM_BWD, flops + ride_flops, 0); // (the riding products are booked here)
     const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform; // as in lstm_forward_persist
     unsigned *err = c->pb_cnt + c->pb_cnt_words - 4;
     {
@@ -99,24 +113,9 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = err;
         a.bias_part = c->pb_bias;
         a.ts = c->pf_ts + 1024;
-        // this step's ride-along jobs (ride_jobs.h) go to the workgroups without a role, if the grid has a free slot group
-        if ((c->tok_job_pending || c->ride_gemm_pending) && (2 * L - 1) * RB < 8 * std::max(1, 32 / NU) &&
-            (!c->tok_job_pending || tok_index_lds(c->ride.tok.VT, c->ride.tok.NP) <= 160 * 1024)) {
+        if (take_jobs) {
             c->ride.has_tok = c->tok_job_pending ? 1 : 0;
             if (!c->ride_gemm_pending) c->ride.ngemm = c->ride.has_colsum = 0;
-            // The products must not lengthen the launch.  Calibration (f32, L = 2, B = 512, T = 26: a 0.90 ms launch, 16 riding
-            // workgroups): 3.2 GFLOP of 64 x 64 tiles (dW_o + dW_q) leave the launch at 0.90 ms, every further 1.07 GFLOP (256 rows
-            // of dW_v) lengthened it by 0.15 ms.  So the load is capped at 3.4 GFLOP per 0.90 ms of launch and 16 riders; a BPTT step
-            // takes ~34 us in f32 (L = 2; ~21 for L = 1) and ~17 us in bf16.  What does not fit is computed behind the launch
-            // (ride_flush).
-            bool keep_gemms = false;
-            if (c->ride.ngemm > 0) {
-                double gf = 0;
-                for (int i = 0; i < c->ride.ngemm; ++i) gf += 2e-9 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
-                const int n_idle = (8 * std::max(1, 32 / NU) - (2 * L - 1) * RB) * NU;
-                const double bptt_ms = 1e-3 * TS * (c->bf16 ? 17.0 : 34.0) * (L == 1 ? 0.62 : 1.0);
-                keep_gemms = gf > 3.4 * (bptt_ms / 0.90) * (n_idle / 16.0);
-            }
             RideJobs kept = c->ride;
             if (keep_gemms) c->ride.ngemm = 0;
             if (!c->ride_dev) NVQA_HIP(hipMalloc((void **)&c->ride_dev, sizeof(RideJobs)));
