@@ -284,10 +284,9 @@ static int create_impl(nvqa_ctx *c)
         }
         if (l > 0) NVQA_TRY(dalloc(&c->U[l], TB * R));
     }
-    NVQA_TRY(dalloc(&c->dCT, L * B * R));
-    NVQA_TRY(dalloc(&c->dHT, L * B * R));
-    NVQA_HIP(hipMemsetAsync(c->dCT, 0, L * B * R * 4, c->s));
-    NVQA_HIP(hipMemsetAsync(c->dHT, 0, L * B * R * 4, c->s)); // NVQA_QUIRK_H0 reads it before the first backward
+    NVQA_TRY(dalloc(&c->dCT, 2 * L * B * R)); // dCT, then dHT: one allocation, so that arch2's per-step clear is one fill
+    c->dHT = c->dCT + L * B * R;
+    NVQA_HIP(hipMemsetAsync(c->dCT, 0, 2 * L * B * R * 4, c->s)); // NVQA_QUIRK_H0 reads dHT before the first backward
     const size_t Q = d.arch == NVQA_ARCH1 ? 2 * R * L : R, C = d.arch == NVQA_ARCH1 ? d.C : 0;
     NVQA_TRY(dalloc(&c->qd, B * Q));
     NVQA_TRY(dalloc(&c->vd, B * d.I));
@@ -373,7 +372,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
             if (q) (void)hipFree(q);
     }
     void *ptrs[] = {c->P, c->G, c->M2, c->qinds, c->sort_idx, c->sort_inv,
-                    c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->dHT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
+                    c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
                     c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->mc,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
     for (void *p : ptrs)
@@ -1201,8 +1200,7 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     const int B = d.B, R = d.R, L = d.L, E = d.E, I = d.I, A = d.A, V = d.V, TS = c->TS, TB = TS * B;
     float *G = c->G;
     // only the top layer's h at step tmax receives a gradient from the head (Encoder_lstm.lua:238-239)
-    NVQA_HIP(hipMemsetAsync(c->dCT, 0, (size_t)L * B * R * 4, c->s));
-    NVQA_HIP(hipMemsetAsync(c->dHT, 0, (size_t)L * B * R * 4, c->s));
+    NVQA_HIP(hipMemsetAsync(c->dCT, 0, (size_t)2 * L * B * R * 4, c->s)); // dCT and dHT (one allocation)
     {
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 4.0 * B * A * R, (2.0 * A * R + 2.0 * B * A) * 4);
         if (ride) ride_add(c, mkargs(c->dscores, A, c->qd, R, A, R, B), EpiStore{G + c->lo.w_o, R, 0});
@@ -1214,7 +1212,21 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
         NVQA_HIP(hipMemcpyAsync(c->Hs[L - 1], c->dHT + (size_t)(L - 1) * B * R, (size_t)B * R * 4, hipMemcpyDeviceToDevice, c->s));
         NVQA_TRY(persist_reimage_h0_top(c)); // ... and so does the bf16 image the weight-gradient kernel stages from
     }
-    NVQA_TRY(colsum(c, c->dscores, B, A, A, G + c->lo.b_o, nullptr));
+    {   // b_o: one B-row column sum (the one-stage form of arch1's head; under the BPTT when the jobs ride)
+        ProfScope ps(c, PF_COLSUM, 0, (double)B * A * 4);
+        ColsumBatch cb = {};
+        cb.X[0] = c->dscores; cb.out[0] = G + c->lo.b_o; cb.M[0] = B; cb.N[0] = A; cb.ld[0] = A;
+        cb.first_block[0] = 0;
+        cb.first_block[1] = cb.first_block[2] = cb.first_block[3] = cb.first_block[4] = (A + 63) / 64;
+        if (ride) {
+            c->ride.cs = cb;
+            c->ride.has_colsum = 1;
+            c->ride_gemm_pending = true;
+        } else {
+            hipLaunchKernelGGL(k_colsum_batch, dim3(cb.first_block[4]), dim3(256), 0, c->s, cb);
+            NVQA_HIP(hipGetLastError());
+        }
+    }
     NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr));
     NVQA_TRY(ride_flush(c));
