@@ -83,7 +83,9 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     // Ride-along jobs (ride_jobs.h): do the idle workgroups exist, and do the weight-gradient products fit?  They must not
     // lengthen the launch.  Calibration (f32, L = 2, B = 512, T = 26: a 0.90 ms launch, 16 riding workgroups): 3.2 GFLOP of
     // 64 x 64 tiles (dW_o + dW_q) leave the launch at 0.90 ms, every further 1.07 GFLOP (256 rows of dW_v) lengthened it by
-    // 0.15 ms.  So the load is capped at 3.4 GFLOP per 0.90 ms of launch and 16 riders; a BPTT step takes ~34 us in f32 (L = 2;
+    // 0.15 ms, then 0.24 ms (a rider runs its 64 x 64 x 512 tiles in 15-17 us each = 0.28 TFLOP/s, 46 % of one CU's f32 peak: one
+    // workgroup of four waves per CU, nothing to overlap its load / store / barrier phases with; two tiles in flight (PF = 2)
+    // changed nothing).  So the load is capped at 3.4 GFLOP per 0.90 ms of launch and 16 riders; a BPTT step takes ~34 us in f32 (L = 2;
     // ~21 for L = 1) and ~17 us in bf16.  What does not fit is computed behind the launch (ride_flush).
     const int n_idle = (8 * std::max(1, 32 / NU) - (2 * L - 1) * RB) * NU;
     const bool take_jobs = (c->tok_job_pending || c->ride_gemm_pending) && n_idle > 0 &&
