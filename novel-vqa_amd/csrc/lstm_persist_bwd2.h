@@ -103,8 +103,9 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     extern __shared__ __attribute__((aligned(16))) float pb2_smem[];
     float *const ring = pb2_smem;                   // [NST][ROWSH][ROWW]: 16-byte pieces, low 4 bits of the piece index XOR-swizzled by the row
     float *const Sred = pb2_smem + NST * STAGE;     // [4 waves][ROWSH][SROW] partial tiles
-    float *const bsum = Sred + 4 * ROWSH * SROW;    // [thread][4 gates][4 units]: sum of the thread's dG over its rows and all steps
-    float *const dcs = bsum + GE::BSUM_FLOATS;      // [thread][half][item][2][4 units]: the carried cell gradient, and c_s of the step just done (= c_{s-1}
+    float *const bsum = Sred + 4 * ROWSH * SROW;    // [4 gates][thread][4 units]: sum of the thread's dG over its rows and all steps (thread-minor:
+                                                    // consecutive lanes -> consecutive 16-byte slots, conflict-free; thread-major strides of 64 / 128 B were 4- / 8-way conflicts)
+    float *const dcs = bsum + GE::BSUM_FLOATS;      // [half][item][2][thread][4 units]: the carried cell gradient, and c_s of the step just done (= c_{s-1}
                                                     // of the next one: the thread owns the same cells at every step) -- thread-private slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS, L = a.L, RBn = a.RB;
@@ -281,16 +282,16 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             const bool ok = erow + RPP * e < 16 * (h ? MTB : MTA) && iloc < nloc;
             pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (!is_up && ok) v = *reinterpret_cast<const pf_f32x4 *>(a.dCT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
-            *reinterpret_cast<pf_f32x4 *>(dcs + (((tid * 2 + h) * NE + e) * 2) * 4) = v; // REC: the carried cell gradient of the owned (row, unit)s
+            *reinterpret_cast<pf_f32x4 *>(dcs + (((h * NE + e) * 2) * NVQA_PF_THREADS + tid) * 4) = v; // REC: the carried cell gradient of the owned (row, unit)s
             {   // ... and the final cell state c_{TS-1} (slice TS of Cs)
                 pf_f32x4 cfin = {0.f, 0.f, 0.f, 0.f};
                 if (!is_up && ok) cfin = *reinterpret_cast<const pf_f32x4 *>(a.Cs[l] + ((size_t)TS * B + grow) * R + u0 + 4 * eq);
-                *reinterpret_cast<pf_f32x4 *>(dcs + (((tid * 2 + h) * NE + e) * 2 + 1) * 4) = cfin;
+                *reinterpret_cast<pf_f32x4 *>(dcs + (((h * NE + e) * 2 + 1) * NVQA_PF_THREADS + tid) * 4) = cfin;
             }
             esi[h][e] = a.sort_idx[ok ? grow : 0];
         }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(bsum + (tid * 4 + g) * 4) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(bsum + (g * NVQA_PF_THREADS + tid) * 4) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 
     // counters
     const unsigned crec = (unsigned)(((l * RBn + rb) * 2) * TS);            // REC(l) counters of this row block: + h * TS + s
@@ -393,10 +394,10 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
         }
         const unsigned go = (unsigned)((srow_g * 4 * R + u0 + 4 * eq) * 4);
         pf_f32x4 dgi = {0.f, 0.f, 0.f, 0.f}, dgf = dgi, dgo = dgi, dgg = dgi, dcn = dgi;
-        pf_f32x4 *dcp = reinterpret_cast<pf_f32x4 *>(dcs + (((tid * 2 + H) * NE + e) * 2) * 4);
+        pf_f32x4 *dcp = reinterpret_cast<pf_f32x4 *>(dcs + (((H * NE + e) * 2) * NVQA_PF_THREADS + tid) * 4); // [0]: dc, [NVQA_PF_THREADS]: c
         if (grow < nr) {
             const pf_f32x4 dc0 = *dcp;
-            const pf_f32x4 ig = e_ig[e], fg = e_fg[e], og = e_og[e], gg = e_gg[e], cc = dcp[1], cp = e_cp[e], v2 = e_v2[e];
+            const pf_f32x4 ig = e_ig[e], fg = e_fg[e], og = e_og[e], gg = e_gg[e], cc = dcp[NVQA_PF_THREADS], cp = e_cp[e], v2 = e_v2[e];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float dh = v[j] + v2[j] + hx[j]; // v2: the UP tile, Dropout' applied by its producer (zeros without one)
@@ -410,14 +411,14 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             }
         }
         *dcp = dcn;
-        dcp[1] = e_cp[e]; // c_{s-1} (slice s of Cs) is the next step's c_s, active row or not
+        dcp[NVQA_PF_THREADS] = e_cp[e]; // c_{s-1} (slice s of Cs) is the next step's c_s, active row or not
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgi), r_g, go, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgf), r_g, go + (unsigned)R * 4, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgo), r_g, go + 2u * R * 4, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgg), r_g, go + 3u * R * 4, 0, 16);
         if (grow < nr) { // bias gradient: column sums of dG (own LDS slot: no other thread touches it)
-            pf_f32x4 *bs = reinterpret_cast<pf_f32x4 *>(bsum + tid * 16);
-            bs[0] += dgi; bs[1] += dgf; bs[2] += dgo; bs[3] += dgg;
+            pf_f32x4 *bs = reinterpret_cast<pf_f32x4 *>(bsum + tid * 4); // gate g at bs[g * NVQA_PF_THREADS]
+            bs[0] += dgi; bs[NVQA_PF_THREADS] += dgf; bs[2 * NVQA_PF_THREADS] += dgo; bs[3 * NVQA_PF_THREADS] += dgg;
         }
         if constexpr (BF) { // the image the REC / UP products read (the f32 one stays what the weight gradients read)
             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
             pf_f32x4 s4[4] = {pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}};
             for (int r = 0; r < RPP; ++r)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) s4[g] += *reinterpret_cast<const pf_f32x4 *>(bsum + ((r * QPR + tid) * 4 + g) * 4);
+                for (int g = 0; g < 4; ++g) s4[g] += *reinterpret_cast<const pf_f32x4 *>(bsum + (g * NVQA_PF_THREADS + r * QPR + tid) * 4);
             float *dst = a.bias_part + ((size_t)l * RBn + rb) * 4 * R + u0 + 4 * tid;
 #pragma unroll
             for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(dst + (size_t)g * R) = s4[g];
