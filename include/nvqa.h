@@ -164,6 +164,14 @@ int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
 #define NVQA_QUIRK_H0 1
 #define NVQA_QUIRK_LOOKUP 2
 int nvqa_set_ref_quirks(nvqa_ctx *ctx, int flags);
+/* torch.norm(cnn_w), torch.norm(encoder_w_q), torch.norm(multimodal_w) of 003_train_vqa_arch2/002_train_baseline.lua:401-403
+ * (arch1: encoder_w_q, embedding_w_q, multimodal_w): the L2 norm of each of the three parameter segments in
+ * nvqa_segments order, reduced on the device.  Synchronises the context's stream. */
+int nvqa_param_norms(nvqa_ctx *ctx, float out[3]);
+/* out[0] / out[1] = 1 when the next training step runs the LSTM forward unroll / the BPTT as ONE persistent launch
+ * (R = 512, E in {200, 512}; BPTT: L <= 2), 0 when it takes the per-level kernels (other shapes, NVQA_PERSIST=0, or after a
+ * reported time-out). */
+int nvqa_persistent_state(const nvqa_ctx *ctx, int out[2]);
 /* Per-segment gradient scale applied before the clamp: {lr_scale, lr_scale, 1} reproduces
  * -lr_scale of 003_train_ae_based_wp.lua:30,344. */
 int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);
@@ -184,6 +192,10 @@ int nvqa_step_indices(nvqa_ctx *ctx, const int64_t *qinds, const nvqa_dropout *d
 #define NVQA_COMM_ID_BYTES 128
 int nvqa_comm_unique_id(void *id_out /* NVQA_COMM_ID_BYTES */);
 int nvqa_comm_init(nvqa_ctx *ctx, int rank, int world, const void *id);
+/* Path of the collective library the nvqa_comm_* entries run on (loads it if that has not happened yet; NULL +
+ * nvqa_last_error() when none can be loaded).  The rule: NVQA_RCCL_LIB if set; else the librccl that sits beside the HIP
+ * runtime image mapped into this process, opened RTLD_LOCAL. */
+const char *nvqa_comm_library(void);
 
 /* ---- VGG-16 fc7 feature extractor (002_train_vqa_arch1/001_prepro_img_vgg.lua) ---- */
 /* Forward only.  width_div = 1 and input_hw = 224 is the real 16-layer VGG (channels

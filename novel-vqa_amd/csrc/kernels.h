@@ -713,14 +713,21 @@ __global__ void k_bias_sum(const float *part /*[RB][N]*/, int RB, int N, float *
     out2[n] = s;
 }
 
-// skip: the sticky err records of the persistent LSTM kernels (8 words, persist_fwd.hip: k_err_latch); dp_skip (data
-// parallel): the number of ranks whose kernel gave up in this step.  While either is set the step's gradients are
-// invalid and nothing is applied -- the host reports the failed step at its next synchronisation point.
+// skip (single process): the sticky err records of the persistent LSTM kernels (8 words, persist_fwd.hip: k_err_latch).
+// dp_skip (data parallel): the number of ranks whose kernel gave up in THIS step, all-reduced -- the same number on every
+// rank.  With a communicator it is the ONLY thing consulted (the launcher passes skip = nullptr): a rank-local sticky record
+// stays set until that rank's host looks, which would make the rank that timed out keep skipping steps the other ranks
+// apply.  While either is set the step's gradients are invalid and nothing is applied; the host reports the
+// failed step at its next synchronisation point -- h_dp[1] (pinned) keeps the count of the LAST failed step until the host
+// clears it, so a later good step does not hide the report on the ranks whose own kernels were fine.
 __global__ void k_rmsprop(float4 *x, const float4 *g, float4 *m, size_t n4, float lr, float alpha,
-                          float eps, float wd, float clamp, float gscale, const unsigned *skip, const float *dp_skip)
+                          float eps, float wd, float clamp, float gscale, const unsigned *skip, const float *dp_skip, float *h_dp)
 {
     if (skip && (skip[0] | skip[4]) != 0u) return;
-    if (dp_skip && dp_skip[0] != 0.f) return;
+    if (dp_skip && dp_skip[0] != 0.f) {
+        if (h_dp && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(h_dp + 1, dp_skip[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const float om = 1.0f - alpha;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -749,6 +756,21 @@ __global__ void k_clamp_copy(const float *g, float *out, size_t n, float clamp, 
     }
 }
 
+
+// sum of squares of x[0..n) in double, one partial per workgroup of 256 threads (nvqa_param_norms)
+__global__ void k_sumsq(const float *x, size_t n, double *part)
+{
+    __shared__ double sh[256];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += (double)x[i] * (double)x[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
 
 __global__ void k_fill(float *p, size_t n, float v)
 {

@@ -5,6 +5,8 @@
 // Reference call stack being replaced: optim.rmsprop -> JdJ
 // (002_train_vqa_arch1/002_train_baseline.lua:272-335,408).
 #include <dlfcn.h>
+#include <limits.h>
+#include <unistd.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,7 +46,7 @@ static const char *kProfNames[PF_COUNT] = {
     "assemble",      "emb_fwd",       "gemm_i2h_fwd", "lstm_step_fwd", "head_prep", "gemm_head_fwd",
     "softmax_ce",    "gemm_head_bwd", "lstm_step_bwd", "gemm_dgrad",   "gemm_wgrad", "reduce_slabs",
     "colsum",        "emb_bwd",       "rmsprop",       "allreduce",    "gather_batch", "lstm_bwd_finish",
-    "transpose_w"};
+    "ride_gemm"};
 
 
 static void prof_collect(nvqa_ctx *c)
@@ -338,6 +340,7 @@ static int create_impl(nvqa_ctx *c)
             if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
         }
         { const char *es = getenv("NVQA_PF_SPIN"); c->pf_spin = es ? (unsigned)strtoul(es, nullptr, 0) : 0u; } // 0: the kernels' default
+        { const char *es = getenv("NVQA_PF_SPIN_STEPS"); c->pf_spin_steps = es ? atoi(es) : -1; } // tests: the limit above holds for the first n training steps only
         NVQA_TRY(dalloc(&c->pf_sticky, 8));
         NVQA_HIP(hipMemsetAsync(c->pf_sticky, 0, 32, c->s));
         NVQA_TRY(dalloc(&c->dp_status, 4));
@@ -348,6 +351,20 @@ static int create_impl(nvqa_ctx *c)
     NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
     *c->h_loss = 0.f;
     NVQA_HIP(hipStreamSynchronize(c->s));
+    {   // The persistent LSTM kernels exist for the shapes the reference trains (rnn_size 512; input_encoding_size 200 or 512;
+        // at most 2 layers for the BPTT): any other -rnn_size runs the per-level kernels (0.48-0.53 of the f32 MFMA peak
+        // instead of 0.60-0.65).  Say so once per process instead of silently being slower (nvqa_persistent_state tells
+        // a host program the same).
+        int RB = 0;
+        const bool fwd = persist_rows(c) > 0, bwd = persist_bwd_rows(c, &RB) > 0;
+        static bool said = false;
+        if ((!fwd || !bwd) && !said && d.R >= 256 && !(getenv("NVQA_QUIET") && atoi(getenv("NVQA_QUIET")))) {
+            fprintf(stderr, "[nvqa] note: R=%d E=%d L=%d B=%d is outside the persistent LSTM kernels' shapes (R = 512, E in {200, 512}%s): "
+                            "forward %s, BPTT %s\n", d.R, d.E, d.L, d.B, d.L > 2 ? ", L <= 2 for the BPTT" : "",
+                    fwd ? "persistent" : "per-level kernels", bwd ? "persistent" : "per-level kernels");
+            said = true;
+        }
+    }
     return 0;
 }
 
@@ -396,6 +413,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->pb_pup) (void)hipFree(c->pb_pup);
     if (c->pf_sticky) (void)hipFree(c->pf_sticky);
     if (c->dp_status) (void)hipFree(c->dp_status);
+    if (c->norm_part) (void)hipFree(c->norm_part);
     if (c->h_dp_status) (void)hipHostFree(c->h_dp_status);
     for (hipEvent_t e : {c->evComm, c->evStart})
         if (e) (void)hipEventDestroy(e);
@@ -449,12 +467,17 @@ static int check_persist(nvqa_ctx *c)
         set_error("%s%s%s; results of that step are invalid and were not applied", fwd, fwd[0] && bwd[0] ? "; " : "", bwd);
         memset(c->h_pf_err, 0, 32);
         (void)hipMemsetAsync(c->pf_sticky, 0, 32, c->s); // reported: k_rmsprop may apply gradients again
+        if (c->comm) { // the same switches and the same cleared status words as the ranks that only see the exchanged count (below)
+            c->persist_on = false; c->persist_bwd_on = 0;
+            if (c->h_dp_status) c->h_dp_status[0] = c->h_dp_status[1] = 0.f;
+        }
         return -3;
     }
-    if (c->comm && c->h_dp_status && c->h_dp_status[0] != 0.f) {
-        set_error("data parallel: the persistent LSTM kernel of %d rank(s) timed out in the last step; no rank applied that step's gradients",
-                  (int)c->h_dp_status[0]);
-        c->h_dp_status[0] = 0.f;
+    if (c->comm && c->h_dp_status && (c->h_dp_status[0] != 0.f || c->h_dp_status[1] != 0.f)) {
+        // [0]: the exchanged count of the last step; [1]: of the last FAILED step (kept by k_rmsprop until cleared here)
+        set_error("data parallel: the persistent LSTM kernel of %d rank(s) timed out in an earlier step; no rank applied that step's gradients",
+                  (int)(c->h_dp_status[0] != 0.f ? c->h_dp_status[0] : c->h_dp_status[1]));
+        c->h_dp_status[0] = c->h_dp_status[1] = 0.f;
         c->persist_on = false; c->persist_bwd_on = 0; // every rank sees the same sum: all of them leave the persistent path together
         return -3;
     }
@@ -467,6 +490,15 @@ extern "C" int nvqa_sync(nvqa_ctx *c)
     NVQA_HIP(hipSetDevice(c->device));
     NVQA_HIP(hipStreamSynchronize(c->s));
     return check_persist(c);
+}
+
+extern "C" int nvqa_persistent_state(const nvqa_ctx *c, int out[2])
+{
+    if (!c || !out) { set_error("NULL argument"); return -1; }
+    int RB = 0;
+    out[0] = persist_rows(c) > 0 ? 1 : 0;
+    out[1] = persist_bwd_rows(c, &RB) > 0 ? 1 : 0;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -504,6 +536,31 @@ static void to_abi(const nvqa_ctx *c, const std::vector<float> &in, float *abi)
         for (size_t v = 0; v < V; ++v)
             for (size_t e = 0; e < E; ++e) dst[e * V + v] = src[v * E + e];
     }
+}
+
+// torch.norm of the three parameter segments (003_train_vqa_arch2/002_train_baseline.lua:400-407 logs them every 100
+// iterations): sums of squares in double on the device (TH accumulates a FloatTensor's norm in double), 6 KB back.
+extern "C" int nvqa_param_norms(nvqa_ctx *c, float out[3])
+{
+    if (!c || !out) { set_error("NULL argument"); return -1; }
+    NVQA_HIP(hipSetDevice(c->device));
+    const int NB = 256;
+    if (!c->norm_part) NVQA_HIP(hipMalloc((void **)&c->norm_part, 3 * NB * sizeof(double)));
+    size_t off = 0;
+    for (int sgm = 0; sgm < 3; ++sgm) {
+        hipLaunchKernelGGL(k_sumsq, dim3(NB), dim3(256), 0, c->s, c->P + off, c->lo.seg[sgm], c->norm_part + sgm * NB);
+        off += c->lo.seg[sgm];
+    }
+    NVQA_HIP(hipGetLastError());
+    std::vector<double> h(3 * NB);
+    NVQA_HIP(hipMemcpyAsync(h.data(), c->norm_part, 3 * NB * sizeof(double), hipMemcpyDeviceToHost, c->s));
+    NVQA_HIP(hipStreamSynchronize(c->s));
+    for (int sgm = 0; sgm < 3; ++sgm) {
+        double t = 0;
+        for (int b = 0; b < NB; ++b) t += h[sgm * NB + b];
+        out[sgm] = (float)sqrt(t);
+    }
+    return check_persist(c);
 }
 
 extern "C" int nvqa_set_params(nvqa_ctx *c, const float *params)
@@ -1255,6 +1312,8 @@ static int batch_release(nvqa_ctx *c); // with upload_batch, below
 static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
 {
     const Drop dr = mkdrop(dropout, true);
+    if (c->pf_spin_steps == 0) c->pf_spin = 0; // (NVQA_PF_SPIN_STEPS: back to the kernels' own limit)
+    if (c->pf_spin_steps > 0) --c->pf_spin_steps;
     if (c->comm) NVQA_HIP(hipMemsetAsync(c->dp_status, 0, 16, c->s));
     if (c->d.arch == NVQA_ARCH1) {
         NVQA_TRY(arch1_forward(c, dr, true, false));
@@ -1509,14 +1568,16 @@ extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps
         const size_t n4 = c->lo.total / 4; // every tensor size is a multiple of 4 (check_dims)
         hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
                            reinterpret_cast<const float4 *>(c->G), reinterpret_cast<float4 *>(c->M2), n4, lr, alpha,
-                           eps, wd, clamp, inv_world * c->gscale[0], c->pf_sticky, c->comm ? c->dp_status : (const float *)nullptr);
+                           eps, wd, clamp, inv_world * c->gscale[0], c->comm ? (const unsigned *)nullptr : c->pf_sticky,
+                           c->comm ? c->dp_status : (const float *)nullptr, c->comm ? c->h_dp_status : (float *)nullptr);
     } else { // -lr_scale of 003_train_ae_based_wp.lua:344: encoder / embedding gradients scaled before the clamp
         size_t off = 0;
         for (int sgm = 0; sgm < 3; ++sgm) {
             const size_t n4 = c->lo.seg[sgm] / 4;
             hipLaunchKernelGGL(k_rmsprop, dim3(1024), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P + off),
                                reinterpret_cast<const float4 *>(c->G + off), reinterpret_cast<float4 *>(c->M2 + off), n4,
-                               lr, alpha, eps, wd, clamp, inv_world * c->gscale[sgm], c->pf_sticky, c->comm ? c->dp_status : (const float *)nullptr);
+                               lr, alpha, eps, wd, clamp, inv_world * c->gscale[sgm], c->comm ? (const unsigned *)nullptr : c->pf_sticky,
+                               c->comm ? c->dp_status : (const float *)nullptr, c->comm ? c->h_dp_status : (float *)nullptr);
             off += c->lo.seg[sgm];
         }
     }
@@ -1611,7 +1672,8 @@ extern "C" int nvqa_step_indices(nvqa_ctx *c, const int64_t *qinds, const nvqa_d
 namespace {
 struct Id128 { char b[128]; }; // ncclUniqueId, passed by value
 struct Rccl {
-    std::string path;
+    std::string path;     // what was asked for: NVQA_RCCL_LIB, or "" = the default rule of load_rccl
+    std::string resolved; // the file the entry points live in
     void *h = nullptr;
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, Id128, int) = nullptr;
@@ -1623,7 +1685,36 @@ struct Rccl {
 // every nvqa_comm_* call, so a process can hold contexts on different libraries): any .so that exports the five nccl*
 // symbols below.  tests/shim/nccl_shim.hip is one whose all-reduce returns world x send, i.e. what `world` ranks with
 // identical gradients produce, so the whole exchange path can be checked on one GPU (tests/test_gpu_dp_shim.py).
+//
+// WHICH librccl.  A process holds ONE HIP runtime image -- libamdhip64.so.7, whichever copy was
+// mapped first: /opt/rocm's when the host loads libnvqa first, the torch wheel's bundled one when the host imported torch
+// first -- and the streams and buffers this library hands to ncclAllReduce belong to that image.  The collective library
+// must be the one built against it, so the rule is: the librccl that sits NEXT TO the mapped libamdhip64 (absolute path,
+// found with dladdr), then the ROCm tree this library was linked against, then the loader's search path.  Always
+// RTLD_LOCAL: round 3 opened it RTLD_GLOBAL, and a second librccl image mapped later (import torch brings its own copy)
+// then interposed its global C++ objects on the first one's -- both ran their destructors at exit ("double free or
+// corruption").  A bare-soname dlopen comes LAST because it silently returns whatever image with that soname is already
+// mapped.  The resolved path is kept (nvqa_comm_library) and printed once per process by nvqa_comm_init.
 std::vector<Rccl *> g_rccl_libs;
+std::string dir_of_mapped_hip()
+{
+    Dl_info di;
+    if (!dladdr((const void *)&hipGetDeviceCount, &di) || !di.dli_fname) return "";
+    char real[PATH_MAX];
+    const std::string f = realpath(di.dli_fname, real) ? real : di.dli_fname;
+    const size_t k = f.rfind('/');
+    return k == std::string::npos ? "" : f.substr(0, k);
+}
+std::string path_of_handle(void *h, const char *sym)
+{
+    Dl_info di;
+    void *p = dlsym(h, sym);
+    if (p && dladdr(p, &di) && di.dli_fname) {
+        char real[PATH_MAX];
+        return realpath(di.dli_fname, real) ? real : di.dli_fname;
+    }
+    return "?";
+}
 const Rccl *load_rccl()
 {
     const char *env = getenv("NVQA_RCCL_LIB");
@@ -1635,10 +1726,21 @@ const Rccl *load_rccl()
         h = dlopen(want.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!h) { set_error("cannot load NVQA_RCCL_LIB=%s: %s", want.c_str(), dlerror()); return nullptr; }
     } else {
-        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) { set_error("cannot load librccl.so: %s", dlerror()); return nullptr; }
+        std::vector<std::string> cand;
+        const std::string hipdir = dir_of_mapped_hip();
+        if (!hipdir.empty()) { cand.push_back(hipdir + "/librccl.so.1"); cand.push_back(hipdir + "/librccl.so"); }
+        const char *rp = getenv("ROCM_PATH");
+        cand.push_back(std::string(rp && rp[0] ? rp : "/opt/rocm") + "/lib/librccl.so.1");
+        cand.push_back("librccl.so.1");
+        cand.push_back("librccl.so");
+        std::string tried;
+        for (const std::string &p : cand) {
+            if (p[0] == '/' && access(p.c_str(), R_OK) != 0) continue;
+            h = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+            tried += (tried.empty() ? "" : "; ") + p + ": " + dlerror();
+        }
+        if (!h) { set_error("cannot load librccl (%s)", tried.c_str()); return nullptr; }
     }
     Rccl *r = new Rccl();
     r->path = want;
@@ -1653,6 +1755,7 @@ const Rccl *load_rccl()
         return nullptr;
     }
     r->h = h;
+    r->resolved = path_of_handle(h, "ncclAllReduce");
     g_rccl_libs.push_back(r);
     return r;
 }
@@ -1667,6 +1770,12 @@ extern "C" int nvqa_comm_unique_id(void *id_out)
     const int rc = r->GetUniqueId(id_out);
     if (rc) { set_error("ncclGetUniqueId: %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
     return 0;
+}
+
+extern "C" const char *nvqa_comm_library(void)
+{
+    const Rccl *r = load_rccl();
+    return r ? r->resolved.c_str() : nullptr;
 }
 
 extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
@@ -1687,10 +1796,33 @@ extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
             char buf[16];
             snprintf(buf, sizeof(buf), "%d", c->comm_cus);
             setenv("NCCL_MAX_NCHANNELS", buf, 0);
+            // What RCCL will actually read: a value the caller exported earlier wins over ours (setenv(..., 0)), and more
+            // channels mean more CUs held by the collective's kernel.  Reserve what is really configured, so that
+            // persist_bwd_rows() refuses the persistent BPTT launch instead of letting its spins expire.  (If RCCL read its
+            // environment earlier in this process -- another communicator -- the cap has no effect on it at all: stated in
+            // INTEGRATION.md; the variable is process-wide and caps every other communicator created after this call.)
+            const char *eff = getenv("NCCL_MAX_NCHANNELS");
+            const int nch = eff ? atoi(eff) : 0;
+            if (nch > c->comm_cus) {
+                static bool said = false;
+                if (!said) {
+                    fprintf(stderr, "[nvqa] NCCL_MAX_NCHANNELS=%d exceeds NVQA_COMM_CUS=%d: reserving %d compute units for the collective\n",
+                            nch, c->comm_cus, nch);
+                    said = true;
+                }
+                c->comm_cus = nch;
+            }
         }
     }
     const Rccl *r = load_rccl();
     if (!r) return -1;
+    {
+        static bool said = false; // once per process: which collective library the data-parallel path runs on
+        if (!said && !(getenv("NVQA_QUIET") && atoi(getenv("NVQA_QUIET")))) {
+            fprintf(stderr, "[nvqa] rank %d/%d: collective library %s\n", rank, world, r->resolved.c_str());
+            said = true;
+        }
+    }
     Id128 idv;
     memcpy(idv.b, id, 128);
     void *comm = nullptr;
@@ -1741,7 +1873,7 @@ static int reduce_join(nvqa_ctx *c)
         const Rccl *r = rccl_of(c);
         const int rc = r->AllReduce(c->dp_status, c->dp_status, 4, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
         if (rc) { set_error("ncclAllReduce (status): %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
-        NVQA_HIP(hipMemcpyAsync(c->h_dp_status, c->dp_status, 16, hipMemcpyDeviceToHost, c->sc));
+        NVQA_HIP(hipMemcpyAsync(c->h_dp_status, c->dp_status, 4, hipMemcpyDeviceToHost, c->sc)); // word 0 only: word 1 of the host copy is k_rmsprop's sticky count
     }
     NVQA_HIP(hipEventRecord(c->evComm, c->sc));
     NVQA_HIP(hipStreamWaitEvent(c->s, c->evComm, 0));

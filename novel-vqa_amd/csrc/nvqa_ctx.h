@@ -49,7 +49,7 @@ enum ProfId {
     PF_ALLREDUCE,
     PF_GATHER,
     PF_LSTM_BWD_FIN, // slab sum + fused cell backward of one BPTT level
-    PF_TRANSPOSE,    // (unused since round 3: the ring kernel that wanted transposed weights is gone; the id keeps the table stable)
+    PF_RIDE,         // FLOPs of the head products that ride in the persistent BPTT launch's idle workgroups (no time of their own: inside PF_LSTM_BWD's launch)
     PF_COUNT
 };
 
@@ -143,6 +143,7 @@ struct nvqa_ctx {
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the sticky err records (forward: words 0-3, BPTT: words 4-7)
     unsigned pf_spin = 0;         // NVQA_PF_SPIN at nvqa_create: polls before a persistent-kernel wait gives up (0: NVQA_PF_SPIN_LIMIT)
+    int pf_spin_steps = -1;       // NVQA_PF_SPIN_STEPS: training steps the NVQA_PF_SPIN limit still applies to (-1: all; a test knob)
     unsigned *pf_sticky = nullptr; // device: first failure of a persistent kernel since the host last looked (persist_fwd.hip: k_err_latch)
     float *dp_status = nullptr, *h_dp_status = nullptr; // data parallel: [0] = ranks whose persistent kernel gave up in this step (summed by the exchange)
     int persist_bwd_on = -1;       // BPTT as one persistent launch (lstm_persist_bwd2.h)
@@ -153,6 +154,7 @@ struct nvqa_ctx {
     int32_t *argmax = nullptr;
     int32_t *mc = nullptr;   // multiple-choice candidates of the batch being evaluated (nvqa_evaluate), allocated on first use
     float *h_loss = nullptr; // pinned
+    double *norm_part = nullptr; // nvqa_param_norms: per-workgroup sums of squares, allocated on first use
 
     nvqa::Dataset ds;
 

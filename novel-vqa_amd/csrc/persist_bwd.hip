@@ -96,7 +96,10 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     const double bptt_ms = 1e-3 * TS * (c->bf16 ? 17.0 : 34.0) * (L == 1 ? 0.62 : 1.0);
     const bool keep_gemms = ride_flops * 1e-9 > 3.4 * (bptt_ms / 0.90) * (n_idle / 16.0);
     if (keep_gemms) ride_flops = 0;
-    ProfScope ps(c, PF_LSTM_BWD, flops + ride_flops, 0); // (the riding products are booked here)
+    // (the riding products are booked under an entry of their own -- they run on CUs the BPTT roles do not use,
+    // and counting their FLOPs in the BPTT phase would flatter its fraction of the peak)
+    if (c->prof_on && ride_flops > 0) { c->prof[PF_RIDE].flops += ride_flops; c->prof[PF_RIDE].launches += 1; }
+    ProfScope ps(c, PF_LSTM_BWD, flops, 0);
     const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform; // as in lstm_forward_persist
     unsigned *err = c->pb_cnt + c->pb_cnt_words - 4;
     {

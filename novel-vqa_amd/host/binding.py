@@ -55,12 +55,15 @@ SYMBOLS = {
     "nvqa_set_fusion": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
     "nvqa_set_ref_quirks": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "nvqa_param_norms": (ctypes.c_int, [_vp, _f32p]),
+    "nvqa_persistent_state": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     "nvqa_set_grad_scales": (ctypes.c_int, [_vp, _f32p]),
     "nvqa_dataset_load": (ctypes.c_int, [_vp, ctypes.c_int64, _i32p, _i32p, _i32p, _i32p,
                                          ctypes.c_int64, _f32p, ctypes.c_int]),
     "nvqa_step_indices": (ctypes.c_int, [_vp, _i64p, ctypes.POINTER(Dropout), _f32p]),
     "nvqa_comm_unique_id": (ctypes.c_int, [_vp]),
     "nvqa_comm_init": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "nvqa_comm_library": (ctypes.c_char_p, []),
     "nvqa_vgg16_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     "nvqa_vgg16_destroy": (ctypes.c_int, [_vp]),
     "nvqa_vgg16_weight_count": (ctypes.c_size_t, [_vp]),
@@ -261,6 +264,18 @@ class Context:
     def sync(self):
         self._check(self.lib.nvqa_sync(self._h))
 
+    def param_norms(self):
+        """torch.norm of the three parameter segments (arch2's training log line, 002_train_baseline.lua:400-407)"""
+        out = np.empty(3, np.float32)
+        self._check(self.lib.nvqa_param_norms(self._h, _f32(out)))
+        return out
+
+    def persistent_state(self):
+        """{'fwd': bool, 'bwd': bool}: does the next step run the LSTM unroll / the BPTT as one persistent launch?"""
+        out = (ctypes.c_int * 2)()
+        self._check(self.lib.nvqa_persistent_state(self._h, out))
+        return {"fwd": bool(out[0]), "bwd": bool(out[1])}
+
     # ---- dataset ------------------------------------------------------------------
     def dataset_load(self, questions, lengths, img_pos, answers, feats, l2_normalize=False):
         q = np.ascontiguousarray(questions, np.int32)
@@ -276,6 +291,13 @@ class Context:
         buf = ctypes.create_string_buffer(COMM_ID_BYTES)
         self._check(self.lib.nvqa_comm_unique_id(ctypes.cast(buf, _vp)))
         return buf.raw
+
+    def comm_library(self):
+        """path of the collective library behind nvqa_comm_* (NVQA_RCCL_LIB, or the librccl beside the mapped HIP runtime)"""
+        p = self.lib.nvqa_comm_library()
+        if p is None:
+            raise NvqaError(f"libnvqa: {self.lib.nvqa_last_error().decode()}")
+        return p.decode()
 
     def comm_init(self, rank, world, comm_id):
         buf = ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)

@@ -35,6 +35,8 @@ int nvqa_rmsprop_update(nvqa_ctx *ctx, float lr, float alpha, float eps, float w
 int nvqa_set_fusion(nvqa_ctx *ctx, int mode);
 int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
 int nvqa_set_ref_quirks(nvqa_ctx *ctx, int flags);
+int nvqa_param_norms(nvqa_ctx *ctx, float out[3]);
+int nvqa_persistent_state(const nvqa_ctx *ctx, int out[2]);
 int nvqa_set_grad_scales(nvqa_ctx *ctx, const float scales[3]);
 int nvqa_dataset_load(nvqa_ctx *ctx, int64_t n_q, const int32_t *questions, const int32_t *lengths,
                       const int32_t *img_pos, const int32_t *answers, int64_t n_img,
@@ -42,6 +44,7 @@ int nvqa_dataset_load(nvqa_ctx *ctx, int64_t n_q, const int32_t *questions, cons
 int nvqa_step_indices(nvqa_ctx *ctx, const int64_t *qinds, const nvqa_dropout *dropout, float *loss_out);
 int nvqa_comm_unique_id(void *id_out);
 int nvqa_comm_init(nvqa_ctx *ctx, int rank, int world, const void *id);
+const char *nvqa_comm_library(void);
 typedef struct nvqa_vgg nvqa_vgg;
 int nvqa_vgg16_create(int device, int width_div, int input_hw, int max_batch, nvqa_vgg **out);
 int nvqa_vgg16_destroy(nvqa_vgg *vgg);

@@ -68,6 +68,9 @@ FULL_BF16 = {
     # one layer: the MT = 4 instances of the forward kernel and the 32-unit (NTN = 2) bf16 instance of the BPTT kernel
     "arch2_L1": dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000),
     "arch1_L1_ragged": dict(arch=1, B=512, T=26, V=14773, E=200, R=512, L=1, I=4096, C=1024, A=1000),
+    # the reference's own default batch (002_train_baseline.lua:31): a last row tile of 4 rows, 12 dead rows per block
+    "arch2_L2_inc_B500": dict(arch=2, B=500, T=26, V=14773, E=512, R=512, L=2, I=2048, C=4, A=1000),
+    "arch1_B500_ragged": dict(arch=1, B=500, T=26, V=14773, E=200, R=512, L=2, I=4096, C=1024, A=1000),
 }
 
 
