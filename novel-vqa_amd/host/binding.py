@@ -119,6 +119,7 @@ class Context:
     def __init__(self, dims, device=0):
         self.lib = load_library()
         self.dims = dims
+        self.fusion = 0  # netdef.AxB until set_fusion says otherwise
         self._h = _vp()
         self._check(self.lib.nvqa_create(ctypes.byref(dims), device, ctypes.byref(self._h)))
 
@@ -246,6 +247,7 @@ class Context:
     def set_fusion(self, mode):
         """0 netdef.AxB, 1 netdef.AskipB, 2 netdef.A_B (W_o becomes [A x 2C]: right after creation only)."""
         self._check(self.lib.nvqa_set_fusion(self._h, int(mode)))
+        self.fusion = int(mode)
 
     QUIRK_H0, QUIRK_LOOKUP = 1, 2
 

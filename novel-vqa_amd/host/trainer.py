@@ -89,6 +89,15 @@ class VQATrainer:
         self.learningRate *= DECAY_FACTOR
         self.iter += 1
 
+    def log_line(self):
+        """The line the training scripts write to save/logFile.txt every 100 iterations: arch1
+        (002_train_baseline.lua:413-416) the running loss, arch2 (003_train_vqa_arch2/002_train_baseline.lua:400-407) the
+        running loss and torch.norm of the three parameter vectors (nvqa_param_norms: reduced on the device)."""
+        if self.dims.arch == 2:
+            n = self.ctx.param_norms()
+            return "iter: %6d train loss: %.3f cnn_norm: %.3f enc_norm: %.3f mm_norm: %.3f" % (self.iter, self.running_avg, n[0], n[1], n[2])
+        return "training loss: %s" % repr(float(self.running_avg))  # (the scripts append 'on iter: i/max_iters')
+
     def train_iteration(self, batch=None):
         f, _ = self.JdJ(batch, want_grads=False)
         self.rmsprop()
@@ -187,6 +196,12 @@ class VQATrainer:
             x[seg[0]:seg[0] + d.E * d.V] = lookup[:, :d.V].ravel()          # Linear(V, E).weight [E x V]
             x[seg[0] + d.E * d.V:seg[0] + seg[1]] = 0.0                      # Linear bias <- 0 (:178)
             if with_multimodal:
+                # 003_train_ae_based_wp.lua:151 builds netdef.AskipB; copying an AE's fusion projections into an AxB model
+                # would train something the reference never does.  (The order of W_q, b_q / W_v, b_v INSIDE the
+                # 'multimodal' tensor is nngraph's as well: PARITY UNPINNED, taken here as W_q, b_q, W_v, b_v.)
+                if self.ctx.fusion != 1:
+                    raise ValueError("with_multimodal=True is the -variant wp path: call ctx.set_fusion(1) (netdef.AskipB) "
+                                     "right after creating the trainer, before any parameters are set")
                 mm = np.asarray(t["multimodal"], np.float32).ravel()
                 n_fuse = d.C * (2 * d.R * d.L) + d.C + d.C * d.I + d.C       # W_q, b_q, W_v, b_v
                 if mm.size != n_fuse:

@@ -106,6 +106,10 @@ do                                                                              
   assert(lookup:size(1) == E and lookup:size(2) == V + 1, 'lookup does not match -input_encoding_size / the vocabulary')
   local enc = savedParams['encoder']:float()
   assert(enc:nElement() == e, 'encoder does not match -rnn_size / -rnn_layer / -input_encoding_size')
+  -- the reference's converter (002_convert_text_model_arch1.lua:27-39) writes nngraph's order and no marker: without a
+  -- permutation only a table this package wrote (layout = 'nvqa') can be copied as it is (host/trainer.py refuses likewise)
+  assert(opt.encoder_perm ~= '' or savedParams.layout == 'nvqa',
+         "the auto-encoder table has no layout = 'nvqa' marker: the order of the LSTM tensors inside 'encoder' is nngraph's; pass -encoder_perm")
   if opt.encoder_perm ~= '' then enc = enc:index(1, torch.load(opt.encoder_perm):long()) end
   x[{{1, e}}]:copy(enc)                                                             -- encoder_w_q:copy(savedParams['encoder'])
   x[{{e + 1, e + E * V}}]:copy(lookup[{{}, {1, lookup:size(2) - 1}}]:contiguous():view(-1))   -- embedding weight (:177)

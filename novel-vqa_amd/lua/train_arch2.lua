@@ -106,6 +106,7 @@ local function save(path)                                                       
                     multimodal_w = x[{{a+b+1,n}}]:clone()})
 end
 
+local norms = ffi.new('float[3]')
 for iter = 1, opt.max_iters do
   if iter % opt.save_checkpoint_every == 0 or iter == 1 then                        -- :393-403
     local loss_val = validate()
@@ -118,9 +119,13 @@ for iter = 1, opt.max_iters do
   -- gradients:clamp(-10,10), then optim.rmsprop with weightDecay (:327, :408; misc/rmsprop_lrscale.lua:16-34)
   nvqa.check(nvqa.lib.nvqa_rmsprop_update(ctx, optimize.learningRate, 0.99, 1e-8, optimize.weightDecay, 10))
   running_avg = running_avg and (running_avg*0.95 + loss[0]*0.05) or loss[0]
-  if iter % 100 == 0 then
-    fileLogger:write('training loss: ' .. running_avg, 'on iter: ' .. iter .. '/' .. opt.max_iters .. '\n')
-    print('training loss: ' .. running_avg, 'on iter: ' .. iter .. '/' .. opt.max_iters)
+  if iter % 100 == 0 then                                                           -- :400-407
+    -- torch.norm(cnn_w), torch.norm(encoder_w_q), torch.norm(multimodal_w): reduced on the device (a 49 MB copy otherwise)
+    nvqa.check(nvqa.lib.nvqa_param_norms(ctx, norms))
+    local line = string.format('iter: %6d train loss: %.3f cnn_norm: %.3f enc_norm: %.3f mm_norm: %.3f',
+                               iter, running_avg, norms[0], norms[1], norms[2])
+    fileLogger:write(line .. '\n')
+    print(line)
   end
   optimize.learningRate = optimize.learningRate * decay_factor                      -- :410
 end

@@ -75,6 +75,8 @@ do                                                                              
   local enc = ae['encoder']:float()
   local n_lstm = b - lk:nElement()
   assert(enc:nElement() == n_lstm, 'encoder does not match -rnn_size / -num_layers / -input_encoding_size')
+  assert(opt.encoder_perm ~= '' or ae.layout == 'nvqa',
+         "the auto-encoder table has no layout = 'nvqa' marker: the order of the LSTM tensors inside 'encoder' is nngraph's; pass -encoder_perm")
   if opt.encoder_perm ~= '' then enc = enc:index(1, torch.load(opt.encoder_perm):long()) end
   x[{{a + 1, a + n_lstm}}]:copy(enc)                                               -- encoder segment: LSTM parameters, then the lookup table
   x[{{a + n_lstm + 1, a + b}}]:copy(lk:contiguous():view(-1))

@@ -51,6 +51,11 @@ def test_arch1_ae_init(pkg, orc, tmp_path, wp):
     mm = rng.standard_normal(n_fuse).astype(np.float32)
     path = str(tmp_path / "ae.t7")
     pkg.t7.save(path, {"lookup": lookup, "encoder": enc, "multimodal": mm, "layout": "nvqa"})
+    if wp:   # the -variant wp path is netdef.AskipB: an AxB context must be refused
+        tr.ctx.fusion = 0
+        with pytest.raises(ValueError):
+            tr.init_from_autoencoder(path, with_multimodal=True)
+        tr.ctx.fusion = 1
     tr.init_from_autoencoder(path, with_multimodal=wp)
     x, (e, m, _) = tr.ctx.x, tr.ctx.seg
     assert np.array_equal(x[:e], enc)

@@ -238,3 +238,29 @@ def test_init_from_autoencoder_through_the_library(pkg, orc, tmp_path):
     ref = orc.Oracle(np.float64).step(d, x, tok, lens, img, lab, orc.Dropout(1, 0.5, tr.dropout_seed, 0))
     assert abs(f - ref["loss"]) <= 2e-6 * abs(ref["loss"])
     tr.close()
+
+
+def test_param_norms_and_arch2_log_line(pkg, orc):
+    """nvqa_param_norms = torch.norm of the three parameter vectors (003_train_vqa_arch2/002_train_baseline.lua:401-403:
+    cnn_w, encoder_w_q, multimodal_w; TH accumulates a FloatTensor's norm in double), reduced on the device, and the log
+    line lua/train_arch2.lua and VQATrainer.log_line() build from it (:404)."""
+    from util import gdims
+    for kw in (dict(arch=2, B=8, T=6, V=300, E=64, R=64, L=2, I=128, C=4, A=40),
+               dict(arch=1, B=8, T=6, V=300, E=40, R=64, L=2, I=128, C=48, A=40)):
+        d = orc.make_dims(**kw)
+        params = orc.synth_params(d)
+        tr = pkg.trainer.VQATrainer(gdims(pkg, d), 0, seed=123)
+        tr.set_params(params)
+        seg = tr.ctx.segments()
+        x = tr.get_params().astype(np.float64)
+        exp, off = [], 0
+        for n in seg:
+            exp.append(np.sqrt((x[off:off + n] ** 2).sum()))
+            off += n
+        got = tr.ctx.param_norms()
+        assert np.allclose(got, exp, rtol=3e-7, atol=0), (got, exp)
+        tr.running_avg, tr.iter = 2.34567, 1200
+        line = tr.log_line()
+        if d.arch == 2:
+            assert line == "iter: %6d train loss: %.3f cnn_norm: %.3f enc_norm: %.3f mm_norm: %.3f" % (1200, 2.34567, exp[0], exp[1], exp[2])
+        tr.close()
