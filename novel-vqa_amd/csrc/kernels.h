@@ -8,6 +8,7 @@
 #include "../../include/nvqa_layout.h"
 #include "epilogues.h"
 #include "gemm_f32.h"
+#include "latch.h"
 
 namespace nvqa {
 
@@ -24,16 +25,57 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// four f32 -> four bf16 (round to nearest even), 8 bytes: a piece of a row of the bf16 image of the layer-0 inputs (bf16 mode: the
+// weight-gradient kernel and, where E = R, the persistent forward kernel read the image instead of rounding f32 rows themselves)
+__device__ __forceinline__ void store_bf16x4(unsigned short *dst, const float4 &v)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    uint2 o;
+    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v.x, v.y}, bf2));
+    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v.z, v.w}, bf2));
+    *reinterpret_cast<uint2 *>(dst) = o;
+}
+
+// W [rows][cols] f32 -> its transpose [cols][rows] in bf16 (round to nearest even), 32 x 32 tiles through LDS: workgroup `blk` of
+// ceil(cols / 32) x ceil(rows / 32), 256 threads.  bf16 mode: the image of W_i2h[0]^T that the gfx950-form d(layer-0 input) product
+// multiplies by (nvqa_api.hip: lstm_dx0); the weights do not move during a step, so it rides as extra workgroups of the
+// embedding launch at the start of the step instead of being a launch of its own in front of the product.
+struct TransposeJob {
+    const float *W = nullptr; // nullptr: no job
+    unsigned short *out = nullptr;
+    int rows = 0, cols = 0, first_block = 0, nblocks = 0;
+};
+__device__ __forceinline__ void transpose_to_bf16_block(const TransposeJob &j, int blk, float (*t)[33])
+{
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nbx = (j.cols + 31) / 32;
+    const int c0 = (blk % nbx) * 32, r0 = (blk / nbx) * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, cc = c0 + tx;
+        t[i][tx] = r < j.rows && cc < j.cols ? j.W[(size_t)r * j.cols + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int cc = c0 + i, r = r0 + tx;
+        if (cc < j.cols && r < j.rows) reinterpret_cast<__bf16 *>(j.out)[(size_t)cc * j.rows + r] = (__bf16)t[tx][i];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // dataset:next_batch() gather (002_train_baseline.lua:202-210): rows qinds of the
 // HBM-resident dataset -> batch buffers.  One block per sample.
 // ---------------------------------------------------------------------------------
-__global__ void k_gather_batch(const int64_t *qinds, const int32_t *Q, const int32_t *QL,
+// The sample ids travel as KERNEL ARGUMENTS (nvqa_step_indices, B <= NVQA_QARG_MAX: 32-bit ids, 3 KB of the 4 KB kernarg
+// segment) -- round 3 copied them with a 4 KB H2D blit in front of every step, a 4.6 us launch of its own; reading them from
+// pinned host memory inside the kernel (one PCIe read per workgroup) measured 11 us SLOWER.  Larger batches: qinds in device memory.
+// (NVQA_QARG_MAX, struct QIdxArg: nvqa_ctx.h)
+template <bool ARG>
+__global__ void k_gather_batch(QIdxArg qa, const int64_t *qinds, const int32_t *Q, const int32_t *QL,
                                const int32_t *IP, const int32_t *ANS, const float *F, int T, int I,
                                int32_t *tok, int32_t *len, int32_t *lab, float *img)
 {
     const int b = blockIdx.x;
-    const int64_t q = qinds[b];
+    const int64_t q = ARG ? (int64_t)qa.q[b] : qinds[b];
     for (int t = threadIdx.x; t < T; t += blockDim.x) tok[(size_t)b * T + t] = Q[q * T + t];
     if (threadIdx.x == 0) {
         len[b] = QL ? QL[q] : T;
@@ -96,27 +138,48 @@ __global__ void k_l2norm_copy(const float *src, int n, int I, float *dst)
 __global__ void k_sort_lengths(const int32_t *len, int B, int T, int32_t *sort_idx, int32_t *sort_inv,
                                int32_t *nrows /*[T]*/)
 {
-    extern __shared__ int sm[]; // hist[T+1], start[T+1], sl[B] (the clamped lengths: the stable rank below reads
-                                // every earlier row's length, from LDS (broadcast reads) instead of from global memory)
-    int *hist = sm, *start = sm + (T + 1), *sl = sm + 2 * (T + 1);
-    for (int i = threadIdx.x; i <= T; i += blockDim.x) hist[i] = 0;
+    // hist[T+1], start[T+1], run[T+1] (rows of each length placed by earlier passes), wcnt[waves][T+1] (rows of each length
+    // in each wave of this pass).  The stable rank of row b among the rows of its length = rows of that length in earlier
+    // passes + in earlier waves of this pass + in lower lanes of its own wave (one ballot per length value: T + 1 ballots
+    // instead of round 3's loop over every earlier row -- 9 us -> the launch floor).
+    extern __shared__ int sm[];
+    const int TL = T + 1, nw = blockDim.x / 64, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int *hist = sm, *start = sm + TL, *run = sm + 2 * TL, *wcnt = sm + 3 * TL;
+    for (int i = threadIdx.x; i < 3 * TL; i += blockDim.x) sm[i] = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += blockDim.x) {
+        const int b = b0 + threadIdx.x;
+        const int l = b < B ? min(max(len[b], 0), T) : -1;
+        int inwave = 0;
+        for (int v = 0; v <= T; ++v) {
+            const unsigned long long m = __ballot(l == v);
+            if (l == v) inwave = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[w * TL + v] = __popcll(m);
+        }
+        __syncthreads();
+        int before = 0;
+        if (l >= 0) {
+            for (int ww = 0; ww < w; ++ww) before += wcnt[ww * TL + l];
+            before += run[l] + inwave;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x <= T) {
+            int tot = 0;
+            for (int ww = 0; ww < nw; ++ww) tot += wcnt[ww * TL + threadIdx.x];
+            run[threadIdx.x] += tot;
+        }
+        // (rank relative to the first row of its length; the bucket starts are known only after the last pass)
+        if (l >= 0) sort_inv[b] = before;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int l = T; l >= 0; --l) { hist[l] = run[l]; start[l] = acc; acc += run[l]; }
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const int l = min(max(len[b], 0), T);
-        sl[b] = l;
-        atomicAdd(&hist[l], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int l = T; l >= 0; --l) { start[l] = acc; acc += hist[l]; }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const int l = sl[b];
-        int rank = 0;
-        for (int c = 0; c < b; ++c) rank += (sl[c] == l);
-        const int pos = start[l] + rank;
+        const int pos = start[l] + sort_inv[b];
         sort_idx[pos] = b;
         sort_inv[b] = pos;
     }
@@ -136,15 +199,24 @@ __global__ void k_sort_lengths(const int32_t *len, int B, int T, int32_t *sort_i
 // ---------------------------------------------------------------------------------
 __global__ void k_emb_fwd(const int32_t *tok, const int32_t *sort_idx, const int32_t *nrows,
                           const float *WeT, const float *be, int B, int T, int E, Drop dr,
-                          float *X, int32_t *ptok)
+                          float *X, int32_t *ptok, unsigned short *Xb /* bf16 image of X, or NULL */, TransposeJob tj)
 {
+    if (tj.W && (int)blockIdx.x >= tj.first_block) {
+        __shared__ float tt[32][33];
+        transpose_to_bf16_block(tj, blockIdx.x - tj.first_block, tt);
+        return;
+    }
     const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
     if (row >= T * B) return;
     const int t = row / B, r = row % B;
     float4 *x4 = reinterpret_cast<float4 *>(X + (size_t)row * E);
+    unsigned short *xb = Xb ? Xb + (size_t)row * E : nullptr;
     if (r >= nrows[t]) {
-        for (int i = lane; i < E / 4; i += 64) x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < E / 4; i += 64) {
+            x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xb) *reinterpret_cast<uint2 *>(xb + 4 * i) = make_uint2(0u, 0u);
+        }
         if (lane == 0) ptok[row] = -1;
         return;
     }
@@ -162,6 +234,7 @@ __global__ void k_emb_fwd(const int32_t *tok, const int32_t *sort_idx, const int
         o.z = tanhf_(dr.scale(NVQA_SITE_EMB, base + 4 * i + 2) * (wv.z + bv.z));
         o.w = tanhf_(dr.scale(NVQA_SITE_EMB, base + 4 * i + 3) * (wv.w + bv.w));
         x4[i] = o;
+        if (xb) store_bf16x4(xb + 4 * i, o);
     }
 }
 
@@ -172,8 +245,9 @@ __global__ void k_emb_fwd(const int32_t *tok, const int32_t *sort_idx, const int
 // ---------------------------------------------------------------------------------
 __global__ void k_head_prep(const float *Cfin /*[L][B][R]*/, const float *Hfin, size_t lstride,
                             const int32_t *sort_inv, const float *img, int B, int R, int L, int I,
-                            Drop dr, float *qd, float *vd)
+                            Drop dr, float *qd, float *vd, LatchArgs latch)
 {
+    if ((int)blockIdx.x == B) { err_latch_block(latch); return; } // the extra workgroup: the forward launch's err latch (latch.h)
     const int b = blockIdx.x, r = sort_inv[b];
     const int Q = 2 * R * L;
     // 16-byte accesses (R % 4 == 0, I % 4 == 0 are preconditions of nvqa_create): 4 consecutive j stay inside
@@ -201,7 +275,7 @@ __global__ void k_head_prep(const float *Cfin /*[L][B][R]*/, const float *Hfin, 
 // One wave per row.  argmax (first maximal index, 1-based) optional.
 // ---------------------------------------------------------------------------------
 __global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, int A, float *dscores,
-                             float *rowloss, int32_t *argmax)
+                             float *rowloss, int32_t *argmax, float *h_rowloss)
 {
     const int b = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
@@ -226,7 +300,14 @@ __global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, 
     sum = wave_sum(sum);
     const float lse = wmx + logf(sum);
     const int y = labels[b] - 1;
-    if (lane == 0) rowloss[b] = lse - s[y];
+    if (lane == 0) {
+        const float rl = lse - s[y];
+        rowloss[b] = rl;
+        // The batch mean is taken by the HOST when it asks for the loss (nvqa_api.hip: loss_mean_host, the fixed order round 3's
+        // one-workgroup k_loss_mean used: bit-identical): the row goes straight into the pinned host array -- a posted PCIe write --
+        // instead of a second launch (4.7 us at the launch floor) and a 4-byte D2H blit (4.6 us) behind this kernel.
+        if (h_rowloss) __hip_atomic_store(h_rowloss + b, rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (dscores) {
         const float invB = 1.0f / (float)B;
         for (int a = lane; a < A; a += 64)
@@ -255,25 +336,13 @@ __global__ void k_mc_argmax(const float *scores, const int32_t *mc, int n, int A
     if (lane == 0) out[b] = cand == 0x7fffffff ? 0 : mc[(size_t)b * n_mc + cand];
 }
 
-// mean of the row losses in a fixed order (single block -> bit-reproducible)
-__global__ void k_loss_mean(const float *rowloss, int B, float *loss)
-{
-    __shared__ float part[256];
-    float s = 0.f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) s += rowloss[b];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = part[0] / (float)B;
-}
-
 // ---------------------------------------------------------------------------------
 // column sums (bias gradients: nn.Linear accGradParameters, gradBias += colsum(dY)).
 // Stage 1: grid (N/64, S): block sums its row stripe for 64 columns -> part[s][n].
 // Stage 2: sums the S partials in order.  Deterministic.
+// (Round 4 tried ONE launch, the last workgroup of a column block adding the partials behind an agent-scope release /
+// acquire pair: the two __threadfence() of every workgroup -- an L2 write-back and an invalidate on a chip whose L2s are
+// full of the GEMMs' dirty lines -- cost more than the second launch: 33 -> 40 us per step.  Two launches stay.)
 // ---------------------------------------------------------------------------------
 __global__ void k_colsum_part(const float *X, int M, int N, int ld, int rows_per_split, float *part)
 {
@@ -494,32 +563,33 @@ __device__ __forceinline__ void emb_seg_sum(const uint16_t *perm, int lo, int hi
     }
 }
 
-// tokens with at most NVQA_ES_SHORT occurrences (absent ones included: their row is zero): one wave per token
+// ONE launch for the whole gradient (round 3: k_emb_bwd_seg + k_emb_bwd_long, two launches):
+//   workgroups [0, gs): tokens with at most NVQA_ES_SHORT occurrences (absent ones included: their row is zero), one wave per token;
+//   workgroups [gs, gs + gl): the frequent tokens: wave (slot, chunk) sums its chunk into a partial row; the last of a token's
+//     NVQA_ES_CHUNKS waves to arrive adds the partials in chunk order; slots beyond *nlong leave at once;
+//   workgroup gs + gl (if present): the err latch of the persistent BPTT launch that ran before (latch.h).
 template <int NPASS>
-__global__ __launch_bounds__(256) void k_emb_bwd_seg(const int32_t *seg_start, const uint16_t *perm, const float *X, const float *dX,
-                                                     const int32_t *sort_idx, int B, int T, int VT, int E, Drop dr, float *dWeT /*[VT][E]*/, int plain)
+__global__ __launch_bounds__(256) void k_emb_bwd_tok(const int32_t *seg_start, const uint16_t *perm, const int32_t *long_tok, const int32_t *nlong,
+                                                     unsigned *done, float *partial /*[slots][CHUNKS][E]*/, unsigned partial_bytes, const float *X,
+                                                     const float *dX, const int32_t *sort_idx, int B, int T, int VT, int E, Drop dr,
+                                                     float *dWeT /*[VT][E]*/, int plain, int gs, int gl, LatchArgs latch)
 {
-    const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= VT) return;
-    const int s0 = seg_start[v], n = seg_start[v + 1] - s0;
-    if (n > NVQA_ES_SHORT) return; // k_emb_bwd_long
-    float4 acc[NPASS];
-    emb_seg_sum<NPASS>(perm, s0, s0 + n, X, dX, sort_idx, B, T, E, dr, plain, lane, acc);
-    float4 *row = reinterpret_cast<float4 *>(dWeT + (size_t)v * E);
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= gs + gl) { err_latch_block(latch); return; }
+    if ((int)blockIdx.x < gs) {
+        const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (v >= VT) return;
+        const int s0 = seg_start[v], n = seg_start[v + 1] - s0;
+        if (n > NVQA_ES_SHORT) return; // a frequent token: the second block range
+        float4 acc[NPASS];
+        emb_seg_sum<NPASS>(perm, s0, s0 + n, X, dX, sort_idx, B, T, E, dr, plain, lane, acc);
+        float4 *row = reinterpret_cast<float4 *>(dWeT + (size_t)v * E);
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-        if (lane + 64 * p < E / 4) row[lane + 64 * p] = acc[p];
-}
-
-// the frequent tokens: wave (slot, chunk) sums its chunk into a partial row; the last of a token's NVQA_ES_CHUNKS waves to
-// arrive adds the partials in chunk order.  Grid = every possible slot; slots beyond *nlong leave at once.
-template <int NPASS>
-__global__ __launch_bounds__(256) void k_emb_bwd_long(const int32_t *seg_start, const uint16_t *perm, const int32_t *long_tok,
-                                                      const int32_t *nlong, unsigned *done, float *partial /*[slots][CHUNKS][E]*/,
-                                                      unsigned partial_bytes, const float *X, const float *dX, const int32_t *sort_idx, int B, int T,
-                                                      int E, Drop dr, float *dWeT, int plain)
-{
-    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+        for (int p = 0; p < NPASS; ++p)
+            if (lane + 64 * p < E / 4) row[lane + 64 * p] = acc[p];
+        return;
+    }
+    const int wv = ((int)blockIdx.x - gs) * 4 + (threadIdx.x >> 6);
     const int slot = wv / NVQA_ES_CHUNKS, ch = wv % NVQA_ES_CHUNKS;
     if (slot >= *nlong) return;
     const int v = long_tok[slot];
@@ -587,20 +657,31 @@ __global__ void k_arch2_tmax(const int32_t *tok, int B, int T, int32_t *nrows /*
 // lookup-table gather for steps >= 1 (Encoder_lstm.lua:177-203); step 0 rows are written by the
 // cnn_projection GEMM.  One wave per (step, sample) row.
 __global__ void k_arch2_embed(const int32_t *tok, const int32_t *tinfo, const float *Wlk, int B, int T, int V, int E,
-                              float *X, int32_t *ptok)
+                              float *X, int32_t *ptok, unsigned short *Xb /* bf16 image of X, or NULL */, TransposeJob tj)
 {
+    if (tj.W && (int)blockIdx.x >= tj.first_block) {
+        __shared__ float tt[32][33];
+        transpose_to_bf16_block(tj, blockIdx.x - tj.first_block, tt);
+        return;
+    }
     const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
     const int TS = T + 2;
     if (row >= TS * B) return;
     const int t = row / B, b = row % B;
-    if (t == 0) {
+    float4 *x4 = reinterpret_cast<float4 *>(X + (size_t)row * E);
+    unsigned short *xb = Xb ? Xb + (size_t)row * E : nullptr;
+    if (t == 0) { // the projected image: written by the projection GEMM in front of this launch; its bf16 image is made here
         if (lane == 0) ptok[row] = -1;
+        if (xb)
+            for (int i = lane; i < E / 4; i += 64) store_bf16x4(xb + 4 * i, x4[i]);
         return;
     }
-    float4 *x4 = reinterpret_cast<float4 *>(X + (size_t)row * E);
     if (t >= tinfo[0]) {
-        for (int i = lane; i < E / 4; i += 64) x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < E / 4; i += 64) {
+            x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xb) *reinterpret_cast<uint2 *>(xb + 4 * i) = make_uint2(0u, 0u);
+        }
         if (lane == 0) ptok[row] = -1;
         return;
     }
@@ -611,12 +692,17 @@ __global__ void k_arch2_embed(const int32_t *tok, const int32_t *tinfo, const fl
     }
     if (lane == 0) ptok[row] = w;
     const float4 *w4 = reinterpret_cast<const float4 *>(Wlk + (size_t)w * E);
-    for (int i = lane; i < E / 4; i += 64) x4[i] = w4[i];
+    for (int i = lane; i < E / 4; i += 64) {
+        const float4 v = w4[i];
+        x4[i] = v;
+        if (xb) store_bf16x4(xb + 4 * i, v);
+    }
 }
 
 // head input: Dropout(h^L at step tmax) (003_.../002_train_baseline.lua:162-164, Encoder_lstm.lua:224)
-__global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int32_t *tinfo, int B, int R, Drop dr, float *hd)
+__global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int32_t *tinfo, int B, int R, Drop dr, float *hd, LatchArgs latch)
 {
+    if ((int)blockIdx.x == B) { err_latch_block(latch); return; } // the extra workgroup: the forward launch's err latch (latch.h)
     const int b = blockIdx.x;
     const float *src = Htop + ((size_t)tinfo[0] * B + b) * R;
     for (int j = threadIdx.x; j < R; j += blockDim.x)

@@ -597,8 +597,16 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_fwd_persist(Persist
     const int grp = blockIdx.x % groups, ut = blockIdx.x / groups;
     const int l = grp / a.RB, rb = grp % a.RB;
     if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4] = wall_clock64();
-    if (l == 0) persist_fwd_layer<G0A, GR, MT, BF, false, RAG>(a, l, rb, ut, pf_smem);
-    else persist_fwd_layer<GR, GR, MT, BF, BF, RAG>(a, l, rb, ut, pf_smem);
+    if constexpr (BF && KA == KR) {
+        // bf16, E = R (arch2): layer 0 reads its input chunks from the bf16 image of X0 (a.Ub[0], left by the embedding kernel)
+        // and is the SAME instance as the layers above -- one copy of the unrolled step loop fewer in the instruction cache;
+        // without the image (NVQA_X0_B16=0) it stages and rounds the f32 rows as before
+        if (l == 0 && !a.Ub[0]) persist_fwd_layer<G0A, GR, MT, BF, false, RAG>(a, l, rb, ut, pf_smem);
+        else persist_fwd_layer<GR, GR, MT, BF, BF, RAG>(a, l, rb, ut, pf_smem);
+    } else {
+        if (l == 0) persist_fwd_layer<G0A, GR, MT, BF, false, RAG>(a, l, rb, ut, pf_smem);
+        else persist_fwd_layer<GR, GR, MT, BF, BF, RAG>(a, l, rb, ut, pf_smem);
+    }
     if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
 }
 template <int KA, int KR, int MT, bool BF> constexpr size_t persist_fwd_lds()

@@ -46,6 +46,9 @@ struct PersistBwd2Args {
     float *Pup[NVQA_PF_MAXL];                         // Pup[l], l < L-1: [TS*B][R] products of the UP(l) role
     unsigned short *Gb[NVQA_PF_MAXL];                 // bf16 instance: [TS*B][4R] bf16 image of dG (written by REC, read as A)
     float *bias_part;                                 // [L][RB][4R]: column sums of dG over the steps and the rows of a row block
+    unsigned *bias_cnt;                               // [L][NU] arrivals of the row blocks of a (layer, unit tile): the last one adds the row blocks'
+    float *bias_i[NVQA_PF_MAXL], *bias_h[NVQA_PF_MAXL]; //   partial sums in row-block order into both bias gradients of the layer (round 3: k_bias_sum,
+                                                      //   one more launch per layer); NULL: the partial sums are all the kernel leaves
     const int *nrows, *sort_idx, *tlast;              // tlast (arch2): dHT enters at step *tlast; NULL (arch1): at TS-1
     unsigned *cnt_rec;                                // [L][RB][2][TS] arrivals of the REC(l) unit tiles, per half
     unsigned *cnt_up;                                 // [L][RB][2][NU][TS] flag of the UP(l) tile, per half
@@ -622,14 +625,43 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     // bias gradients of this (layer, row block, unit tile): the row groups' partial sums added in a fixed order
     if (!is_up && a.bias_part) {
         __syncthreads();
+        const __amdgpu_buffer_rsrc_t r_bp = pf_rsrc(a.bias_part, (size_t)L * RBn * 4 * R * 4);
         if (tid < QPR) { // thread eq: the RPP threads (erow = 0 .. RPP-1) that own the same unit quad
             pf_f32x4 s4[4] = {pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}, pf_f32x4{0.f, 0.f, 0.f, 0.f}};
             for (int r = 0; r < RPP; ++r)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) s4[g] += *reinterpret_cast<const pf_f32x4 *>(bsum + (g * NVQA_PF_THREADS + r * QPR + tid) * 4);
-            float *dst = a.bias_part + ((size_t)l * RBn + rb) * 4 * R + u0 + 4 * tid;
+            // (write-through stores: the workgroup that adds the row blocks' sums below may sit on another XCD)
+            const unsigned doff = (unsigned)((((size_t)l * RBn + rb) * 4 * R + u0 + 4 * tid) * 4);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(dst + (size_t)g * R) = s4[g];
+            for (int g = 0; g < 4; ++g) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, s4[g]), r_bp, doff + (unsigned)g * R * 4, 0, 16 /* sc1 */);
+        }
+        if (a.bias_cnt) {
+            // b_i2h and b_h2h of this layer's units u0 .. u0 + UNITS - 1: the row blocks' sums added in row-block order (the order of
+            // round 3's k_bias_sum launches: bit-identical) by whichever of the RBn workgroups of this (layer, unit tile) finishes
+            // last.  Hand-off as everywhere in this kernel (MI355X_MICROARCH.md "Valid forms", first row of the table): sc1 stores,
+            // drained by the storing waves, the workgroup's barrier, ONE agent-scope add by one lane; the workgroup whose add came
+            // last -- told by the value returned -- reads all partial sums with sc1 loads behind a barrier its adding wave joins;
+            // it re-arms the counter.  (An agent-scope fence pair instead -- __threadfence() -- is an L2 write-back and an invalidate
+            // per workgroup on a chip whose L2s hold this launch's dirty dG lines: measured slower than the launches it saves.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned *const flag = reinterpret_cast<unsigned *>(ring); // (the ring is dead by now)
+            if (tid == 0) *flag = __hip_atomic_fetch_add(a.bias_cnt + l * a.NU + ut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag == (unsigned)RBn - 1) {
+                if (tid < QPR) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        pf_f32x4 s4 = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int r = 0; r < RBn; ++r)
+                            s4 += __builtin_bit_cast(pf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bp, (unsigned)((((size_t)l * RBn + r) * 4 * R + (size_t)g * R + u0 + 4 * tid) * 4), 0, 16 /* sc1 */));
+                        *reinterpret_cast<pf_f32x4 *>(a.bias_i[l] + (size_t)g * R + u0 + 4 * tid) = s4;
+                        *reinterpret_cast<pf_f32x4 *>(a.bias_h[l] + (size_t)g * R + u0 + 4 * tid) = s4;
+                    }
+                }
+                if (tid == 0) __hip_atomic_store(a.bias_cnt + l * a.NU + ut, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();

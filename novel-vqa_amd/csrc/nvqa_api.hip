@@ -177,9 +177,8 @@ static int check_dims(const nvqa_dims *d)
         set_error("arch2: T=%d exceeds the %d question steps k_arch2_tmax supports", d->T, NVQA_ARCH2_TMAX);
         return -1;
     }
-    if (d->arch == NVQA_ARCH1 && (2 * ((size_t)d->T + 1) + (size_t)d->B) * sizeof(int) > 64 * 1024) {
-        set_error("arch1: B=%d, T=%d need %zu bytes of LDS in k_sort_lengths (limit 65536)", d->B, d->T,
-                  (2 * ((size_t)d->T + 1) + (size_t)d->B) * sizeof(int));
+    if (d->arch == NVQA_ARCH1 && (3 + 16) * ((size_t)d->T + 1) * sizeof(int) > 64 * 1024) {
+        set_error("arch1: T=%d needs %zu bytes of LDS in k_sort_lengths (limit 65536)", d->T, (3 + 16) * ((size_t)d->T + 1) * sizeof(int));
         return -1;
     }
     return 0;
@@ -289,6 +288,7 @@ static int create_impl(nvqa_ctx *c)
     NVQA_TRY(dalloc(&c->dCT, 2 * L * B * R)); // dCT, then dHT: one allocation, so that arch2's per-step clear is one fill
     c->dHT = c->dCT + L * B * R;
     NVQA_HIP(hipMemsetAsync(c->dCT, 0, 2 * L * B * R * 4, c->s)); // NVQA_QUIRK_H0 reads dHT before the first backward
+    c->dct_zero = true;
     const size_t Q = d.arch == NVQA_ARCH1 ? 2 * R * L : R, C = d.arch == NVQA_ARCH1 ? d.C : 0;
     NVQA_TRY(dalloc(&c->qd, B * Q));
     NVQA_TRY(dalloc(&c->vd, B * d.I));
@@ -300,7 +300,6 @@ static int create_impl(nvqa_ctx *c)
     NVQA_TRY(dalloc(&c->scores, B * d.A));
     NVQA_TRY(dalloc(&c->dscores, B * d.A));
     NVQA_TRY(dalloc(&c->rowloss, B));
-    NVQA_TRY(dalloc(&c->d_loss, 1));
     NVQA_TRY(dalloc(&c->argmax, B));
     // scratch: column-sum partials (64 splits x widest matrix) and split-K slabs
     const size_t widest = std::max<size_t>(std::max<size_t>(4 * R, d.I), std::max<size_t>(d.A, std::max<size_t>(E, C)));
@@ -337,6 +336,11 @@ static int create_impl(nvqa_ctx *c)
             NVQA_TRY(dalloc(&c->pb_cnt, c->pb_cnt_words));
             NVQA_HIP(hipMemsetAsync(c->pb_cnt, 0, c->pb_cnt_words * 4, c->s));
             NVQA_TRY(dalloc(&c->pb_bias, L * rbmax * 4 * R));
+            const char *ebb = getenv("NVQA_BIAS_IN_BPTT"); // 0: the row blocks' sums are added by k_bias_sum launches (A/B runs)
+            if (!(ebb && ebb[0] == '0')) {
+                NVQA_TRY(dalloc(&c->pb_bias_cnt, L * 32));
+                NVQA_HIP(hipMemsetAsync(c->pb_bias_cnt, 0, L * 32 * 4, c->s));
+            }
             if (L > 1) NVQA_TRY(dalloc(&c->pb_pup, (L - 1) * TS * B * R));
         }
         { const char *es = getenv("NVQA_PF_SPIN"); c->pf_spin = es ? (unsigned)strtoul(es, nullptr, 0) : 0u; } // 0: the kernels' default
@@ -348,8 +352,9 @@ static int create_impl(nvqa_ctx *c)
         NVQA_HIP(hipHostMalloc((void **)&c->h_dp_status, 4 * sizeof(float), hipHostMallocDefault));
         memset(c->h_dp_status, 0, 16);
     }
-    NVQA_HIP(hipHostMalloc((void **)&c->h_loss, sizeof(float), hipHostMallocDefault));
-    *c->h_loss = 0.f;
+    NVQA_HIP(hipHostMalloc((void **)&c->h_rowloss, B * sizeof(float), hipHostMallocDefault)); // k_softmax_ce writes the row losses here
+    memset(c->h_rowloss, 0, B * sizeof(float));
+    c->loss_rows = (int)B;
     NVQA_HIP(hipStreamSynchronize(c->s));
     {   // The persistent LSTM kernels exist for the shapes the reference trains (rnn_size 512; input_encoding_size 200 or 512;
         // at most 2 layers for the BPTT): any other -rnn_size runs the per-level kernels (0.48-0.53 of the f32 MFMA peak
@@ -390,7 +395,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     }
     void *ptrs[] = {c->P, c->G, c->M2, c->qinds, c->sort_idx, c->sort_inv,
                     c->nrows, c->ptok, c->tinfo, c->X0, c->dX0, c->dCT, c->qd, c->vd, c->qc, c->ic, c->zd, c->dqc,
-                    c->dic, c->scores, c->dscores, c->rowloss, c->d_loss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->mc,
+                    c->dic, c->scores, c->dscores, c->rowloss, c->argmax, c->colpart, c->slabs, c->chain_slabs, c->mc,
                     c->ds.Q, c->ds.QL, c->ds.IP, c->ds.ANS, c->ds.F, c->seg_start, c->pslot, c->perm, c->seg_done, c->seg_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -400,7 +405,7 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
         if (l == 0 && c->Cs[l]) (void)hipFree(c->Cs[l]);
         if (c->U[l]) (void)hipFree(c->U[l]);
     }
-    if (c->h_loss) (void)hipHostFree(c->h_loss);
+    if (c->h_rowloss) (void)hipHostFree(c->h_rowloss);
     if (c->h_pf_err) (void)hipHostFree(c->h_pf_err);
     if (c->pf_cnt) (void)hipFree(c->pf_cnt);
     if (c->pf_ts) (void)hipFree(c->pf_ts);
@@ -410,6 +415,8 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     if (c->ride_dev) (void)hipFree(c->ride_dev);
     if (c->pb_cnt) (void)hipFree(c->pb_cnt);
     if (c->pb_bias) (void)hipFree(c->pb_bias);
+    if (c->pb_bias_cnt) (void)hipFree(c->pb_bias_cnt);
+    if (c->x0_b16) (void)hipFree(c->x0_b16);
     if (c->pb_pup) (void)hipFree(c->pb_pup);
     if (c->pf_sticky) (void)hipFree(c->pf_sticky);
     if (c->dp_status) (void)hipFree(c->dp_status);
@@ -429,6 +436,25 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
 }
 
 // after the stream has drained: did a persistent-kernel wait give up? (lstm_persist.h: every spin is bounded)
+// mean of the first loss_rows row losses (pinned host array written by k_softmax_ce) in the FIXED order of round 3's device
+// kernel k_loss_mean -- 256 strided partial sums, then a binary tree -- so the value is bit-identical to what that kernel
+// produced and does not depend on the host's vector width (f32 adds only, no contraction possible).  Call after the
+// stream has been synchronised.
+static float loss_mean_host(const nvqa_ctx *c)
+{
+    volatile const float *r = c->h_rowloss;
+    const int n = c->loss_rows;
+    float part[256];
+    for (int i = 0; i < 256; ++i) {
+        float s = 0.f;
+        for (int b = i; b < n; b += 256) s += r[b];
+        part[i] = s;
+    }
+    for (int o = 128; o > 0; o >>= 1)
+        for (int i = 0; i < o; ++i) part[i] += part[i + o];
+    return part[0] / (float)n;
+}
+
 static int check_persist(nvqa_ctx *c)
 {
     static const int ts_dbg = [] { const char *a = getenv("NVQA_PF_DBG"), *b = getenv("NVQA_PB_DBG"); return ((a ? atoi(a) : 0) | (b ? atoi(b) : 0)) & 32; }();
@@ -724,6 +750,7 @@ static int lstm_forward(nvqa_ctx *c, const Drop &dr)
     const int B = d.B, R = d.R, L = d.L, TS = c->TS, TB = TS * B;
     c->img_fwd_valid = c->img_bwd_valid = false;
     c->pb_bias_rb = 0;
+    c->pb_bias_done = false;
     if (const int MT = persist_rows(c)) { c->img_fwd_valid = c->bf16; return lstm_forward_persist(c, dr, MT); }
     // Layer 0 takes W_i2h x_t as a first K segment inside the level kernel, like the layers above it: the
     // time-batched projection (0.128 ms, a 109 MB write and its re-read by the level epilogues) costs more than
@@ -803,6 +830,7 @@ static int lstm_backward(nvqa_ctx *c, const Drop &dr)
     // ragged arch1 batches (or lengths known only on the device): the products pick their split-K depth from nrows[s] on
     // the device -- a level with 2 of 8 row tiles active runs 16 short K slices instead of 4 long ones; the launch's workgroups are
     // re-dealt over (active row tile, column tile, slice).  NVQA_BWD_ZADAPT=0 switches it off.
+    c->dct_zero = false; // (the per-level finisher carries the cell gradient in dCT, in place)
     static const bool zad_on = [] { const char *e = getenv("NVQA_BWD_ZADAPT"); return !(e && e[0] == '0'); }();
     const bool zad = zad_on && d.arch == NVQA_ARCH1 && !c->batch_uniform && (4 * R) % (NVQA_BWD_ZMAX * 32) == 0;
     const int Zl = zad ? NVQA_BWD_ZMAX : NVQA_BWD_Z;
@@ -898,10 +926,13 @@ static int lstm_wgrads(nvqa_ctx *c, int l)
     const size_t hs = (size_t)(c->TS + 1) * d.B * R, us = (size_t)c->TS * d.B * R;
     const unsigned short *G16 = c->img_bwd_valid ? c->dg_b16 + (size_t)l * TB * 4 * R : nullptr;
     const unsigned short *H16 = c->img_fwd_valid ? c->act_b16 + l * hs : nullptr;
-    const unsigned short *X16 = c->img_fwd_valid && l > 0 ? c->act_b16 + d.L * hs + l * us : nullptr;
+    const unsigned short *X16 = l == 0 ? (c->x0_img_valid ? c->x0_b16 : nullptr)
+                                       : (c->img_fwd_valid ? c->act_b16 + d.L * hs + l * us : nullptr);
     NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, c->Hs[l], R, 4 * R, R, TB, c->G + c->lo.w_h2h[l], c->slabs, c->s, G16, H16));
     NVQA_TRY(wgrad(c, c->Gt[l], 4 * R, Xin, in, 4 * R, in, TB, c->G + c->lo.w_i2h[l], c->slabs, c->s, G16, X16));
-    if (c->pb_bias_rb > 0) { // the persistent BPTT kernel of this step left the column sums per row block (lstm_persist_bwd2.h)
+    if (c->pb_bias_rb > 0 && c->pb_bias_done) {
+        // the persistent BPTT kernel of this step wrote both bias gradients of every layer itself (its last workgroup per unit tile)
+    } else if (c->pb_bias_rb > 0) { // ... or left the column sums per row block (lstm_persist_bwd2.h; NVQA_BIAS_IN_BPTT=0)
         ProfScope ps(c, PF_COLSUM, 0, (double)c->pb_bias_rb * 4 * R * 4);
         hipLaunchKernelGGL(k_bias_sum, dim3((4 * R + 255) / 256), dim3(256), 0, c->s, c->pb_bias + (size_t)l * c->pb_bias_rb * 4 * R, c->pb_bias_rb,
                            4 * R, c->G + c->lo.b_i2h[l], c->G + c->lo.b_h2h[l]);
@@ -929,6 +960,12 @@ __global__ void k_transpose_to_bf16(const float *W, int rows, int cols, __bf16 *
     }
 }
 
+static bool dx0_b2_enabled() // NVQA_DX0_B2=0: d(layer-0 input) in the BF = 1 form (A/B runs)
+{
+    static const bool on = [] { const char *e = getenv("NVQA_DX0_B2"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // dL/d(layer-0 input) for all steps at once; runs after the LSTM weight gradients so that their
 // all-reduce (data parallel) overlaps it.
 static int lstm_dx0(nvqa_ctx *c, float *dX0)
@@ -940,11 +977,12 @@ static int lstm_dx0(nvqa_ctx *c, float *dX0)
     // bf16 image of W_i2h (made here, per step: the weights move) both operands are K-contiguous bf16 and the product runs
     // in the gfx950 form (BF = 2: bf16 LDS images, v_mfma_f32_16x16x32_bf16) instead of rounding f32 LDS images per MFMA.
     // Same operand values, f32 accumulate, f32 result.  NVQA_DX0_B2=0: the BF = 1 form (A/B runs).
-    static const bool b2_on = [] { const char *e = getenv("NVQA_DX0_B2"); return !(e && e[0] == '0'); }();
-    if (c->bf16 && c->img_bwd_valid && b2_on && (4 * R) % 64 == 0) {
-        if (!c->wi2h0_t16) NVQA_HIP(hipMalloc((void **)&c->wi2h0_t16, (size_t)d.E * 4 * R * 2));
-        hipLaunchKernelGGL(k_transpose_to_bf16, dim3((d.E + 31) / 32, (4 * R + 31) / 32), dim3(32, 8), 0, c->s, c->P + c->lo.w_i2h[0], 4 * R, d.E,
-                           reinterpret_cast<__bf16 *>(c->wi2h0_t16));
+    if (c->bf16 && c->img_bwd_valid && dx0_b2_enabled() && (4 * R) % 64 == 0) {
+        if (!c->wi2h0_img_step) { // (normally made by the embedding launch of this step: wi2h0_image_job)
+            if (!c->wi2h0_t16) NVQA_HIP(hipMalloc((void **)&c->wi2h0_t16, (size_t)d.E * 4 * R * 2));
+            hipLaunchKernelGGL(k_transpose_to_bf16, dim3((d.E + 31) / 32, (4 * R + 31) / 32), dim3(32, 8), 0, c->s, c->P + c->lo.w_i2h[0], 4 * R, d.E,
+                               reinterpret_cast<__bf16 *>(c->wi2h0_t16));
+        }
         GemmArgs g = {};
         g.A = reinterpret_cast<const float *>(c->dg_b16); g.lda = 4 * R / 2; // sizes in storage floats (two bf16)
         g.B = reinterpret_cast<const float *>(c->wi2h0_t16); g.ldb = 4 * R / 2;
@@ -1021,11 +1059,12 @@ static int emb_backward(nvqa_ctx *c, int VT, int NP, int T, const float *dX, con
     if (emb_index_ok(c, VT, NP)) {
         const int slots = NP / NVQA_ES_SHORT + 2; // c->pslot: [slots] tokens of the long segments, then their number
         const int32_t *nlong = c->pslot + slots;
-        const dim3 gs((VT + 3) / 4), gl((slots * NVQA_ES_CHUNKS + 3) / 4);
-#define NVQA_ES_GO(NP_)                                                                                                                     \
-    hipLaunchKernelGGL(k_emb_bwd_seg<NP_>, gs, dim3(256), 0, c->s, c->seg_start, c->perm, c->X0, dX, c->sort_idx, B, T, VT, E, dr, dWeT, plain);  \
-    hipLaunchKernelGGL(k_emb_bwd_long<NP_>, gl, dim3(256), 0, c->s, c->seg_start, c->perm, c->pslot, nlong, c->seg_done, c->seg_part,         \
-                       (unsigned)c->seg_part_bytes, c->X0, dX, c->sort_idx, B, T, E, dr, dWeT, plain)
+        const int gs = (VT + 3) / 4, gl = (slots * NVQA_ES_CHUNKS + 3) / 4;
+        const LatchArgs la = latch_take(c, 1); // the BPTT launch's err latch rides as the last workgroup (latch.h)
+        const dim3 grid(gs + gl + (la.cnt ? 1 : 0));
+#define NVQA_ES_GO(NP_)                                                                                                                        \
+    hipLaunchKernelGGL(k_emb_bwd_tok<NP_>, grid, dim3(256), 0, c->s, c->seg_start, c->perm, c->pslot, nlong, c->seg_done, c->seg_part,          \
+                       (unsigned)c->seg_part_bytes, c->X0, dX, c->sort_idx, B, T, VT, E, dr, dWeT, plain, gs, gl, la)
         if (E <= 256) { NVQA_ES_GO(1); } else { NVQA_ES_GO(2); }
 #undef NVQA_ES_GO
     } else {
@@ -1039,6 +1078,35 @@ static int emb_backward(nvqa_ctx *c, int VT, int NP, int T, const float *dX, con
     return 0;
 }
 
+// bf16 mode: the embedding kernels also leave a bf16 image of the layer-0 inputs -- the B operand of layer 0's input weight
+// gradient (k_wgrad_bf16<true, true>: 47 instead of 58 us) and, where E = R (arch2), the persistent forward kernel's layer-0
+// input segment (half the bytes per chunk, no rounding on the way into LDS).  Same values: f32 rounded to nearest even.
+static int x0_image_begin(nvqa_ctx *c, int TB)
+{
+    c->x0_img_valid = false;
+    static const bool on = [] { const char *e = getenv("NVQA_X0_B16"); return !(e && e[0] == '0'); }();
+    if (!c->bf16 || !on || c->d.E % 8) return 0;
+    if (!c->x0_b16) NVQA_HIP(hipMalloc((void **)&c->x0_b16, (size_t)TB * c->d.E * 2));
+    c->x0_img_valid = true;
+    return 0;
+}
+
+// bf16 mode, training step, persistent BPTT ahead: the bf16 image of W_i2h[0]^T that lstm_dx0's gfx950-form product wants is
+// made by extra workgroups of the embedding launch (the weights do not move during a step).
+static int wi2h0_image_job(nvqa_ctx *c, bool train, int first_block, TransposeJob *tj)
+{
+    *tj = TransposeJob{};
+    c->wi2h0_img_step = false;
+    int rb = 0;
+    const int R = c->d.R, E = c->d.E;
+    if (!train || !c->bf16 || !dx0_b2_enabled() || (4 * R) % 64 || persist_bwd_rows(c, &rb) == 0) return 0;
+    if (!c->wi2h0_t16) NVQA_HIP(hipMalloc((void **)&c->wi2h0_t16, (size_t)E * 4 * R * 2));
+    tj->W = c->P + c->lo.w_i2h[0]; tj->out = c->wi2h0_t16; tj->rows = 4 * R; tj->cols = E;
+    tj->first_block = first_block; tj->nblocks = ((E + 31) / 32) * ((4 * R + 31) / 32);
+    c->wi2h0_img_step = true;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // arch1
 // ------------------------------------------------------------------------------------
@@ -1049,21 +1117,25 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     const int TB = T * B;
     {
         ProfScope ps(c, PF_ASSEMBLE);
-        hipLaunchKernelGGL(k_sort_lengths, dim3(1), dim3(1024), (2 * (T + 1) + B) * sizeof(int), c->s, c->len, B, T,
+        hipLaunchKernelGGL(k_sort_lengths, dim3(1), dim3(1024), (3 + 16) * (T + 1) * sizeof(int), c->s, c->len, B, T,
                            c->sort_idx, c->sort_inv, c->nrows);
     }
     {
         ProfScope ps(c, PF_EMB_FWD, 0, 2.0 * TB * E * 4);
-        hipLaunchKernelGGL(k_emb_fwd, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->sort_idx, c->nrows,
-                           c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok);
+        NVQA_TRY(x0_image_begin(c, TB));
+        TransposeJob tj;
+        NVQA_TRY(wi2h0_image_job(c, train, (TB + 3) / 4, &tj));
+        hipLaunchKernelGGL(k_emb_fwd, dim3((TB + 3) / 4 + tj.nblocks), dim3(256), 0, c->s, c->tok, c->sort_idx, c->nrows,
+                           c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok, c->x0_img_valid ? c->x0_b16 : nullptr, tj);
     }
     NVQA_HIP(hipGetLastError());
     NVQA_TRY(lstm_forward(c, dr));
     if (train) NVQA_TRY(emb_index_begin(c, d.V, TB));
     {
         ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * (Q + I) * 4);
-        hipLaunchKernelGGL(k_head_prep, dim3(B), dim3(256), 0, c->s, c->Cs[0] + (size_t)T * B * R,
-                           c->Hs[0] + (size_t)T * B * R, (size_t)(T + 1) * B * R, c->sort_inv, c->img, B, R, L, I, dr, c->qd, c->vd);
+        const LatchArgs la = latch_take(c, 0); // the forward launch's err latch rides as an extra workgroup (latch.h)
+        hipLaunchKernelGGL(k_head_prep, dim3(B + (la.cnt ? 1 : 0)), dim3(256), 0, c->s, c->Cs[0] + (size_t)T * B * R,
+                           c->Hs[0] + (size_t)T * B * R, (size_t)(T + 1) * B * R, c->sort_inv, c->img, B, R, L, I, dr, c->qd, c->vd, la);
     }
     NVQA_HIP(hipGetLastError());
     {
@@ -1099,8 +1171,8 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
         ProfScope ps(c, PF_SOFTMAX_CE, 0, 2.0 * B * A * 4);
         hipLaunchKernelGGL(k_softmax_ce, dim3((B + 3) / 4), dim3(256), 0, c->s, c->scores,
                            train ? c->lab : (const int32_t *)nullptr, B, A, train ? c->dscores : (float *)nullptr,
-                           c->rowloss, want_argmax ? c->argmax : (int32_t *)nullptr);
-        if (train) hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(256), 0, c->s, c->rowloss, B, c->d_loss);
+                           c->rowloss, want_argmax ? c->argmax : (int32_t *)nullptr, train ? c->h_rowloss : (float *)nullptr);
+        if (train) c->loss_rows = B;
     }
     NVQA_HIP(hipGetLastError());
     return 0;
@@ -1223,7 +1295,11 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     }
     {
         ProfScope ps(c, PF_EMB_FWD, 0, 2.0 * TB * E * 4);
-        hipLaunchKernelGGL(k_arch2_embed, dim3((TB + 3) / 4), dim3(256), 0, c->s, c->tok, c->tinfo, c->P + c->lo.w_lk, B, T, d.V, E, c->X0, c->ptok);
+        NVQA_TRY(x0_image_begin(c, TB));
+        TransposeJob tj;
+        NVQA_TRY(wi2h0_image_job(c, train, (TB + 3) / 4, &tj));
+        hipLaunchKernelGGL(k_arch2_embed, dim3((TB + 3) / 4 + tj.nblocks), dim3(256), 0, c->s, c->tok, c->tinfo, c->P + c->lo.w_lk, B, T, d.V, E, c->X0, c->ptok,
+                           c->x0_img_valid ? c->x0_b16 : nullptr, tj);
     }
     NVQA_HIP(hipGetLastError());
     if (c->quirks & NVQA_QUIRK_H0) // top-layer h0 = what the last backward left in the aliased tensor (Encoder_lstm.lua:238-239)
@@ -1232,7 +1308,8 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     if (train && !(c->quirks & NVQA_QUIRK_LOOKUP)) NVQA_TRY(emb_index_begin(c, d.V + 1, TB));
     {
         ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * R * 4);
-        hipLaunchKernelGGL(k_arch2_head_prep, dim3(B), dim3(256), 0, c->s, c->Hs[L - 1], c->tinfo, B, R, dr, c->qd);
+        const LatchArgs la = latch_take(c, 0);
+        hipLaunchKernelGGL(k_arch2_head_prep, dim3(B + (la.cnt ? 1 : 0)), dim3(256), 0, c->s, c->Hs[L - 1], c->tinfo, B, R, dr, c->qd, la);
     }
     {   // scores = Linear(R, A)(Dropout(h))
         ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * A * R, ((double)B * R + (double)A * R) * 4);
@@ -1243,8 +1320,8 @@ static int arch2_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
         ProfScope ps(c, PF_SOFTMAX_CE, 0, 2.0 * B * A * 4);
         hipLaunchKernelGGL(k_softmax_ce, dim3((B + 3) / 4), dim3(256), 0, c->s, c->scores,
                            train ? c->lab : (const int32_t *)nullptr, B, A, train ? c->dscores : (float *)nullptr,
-                           c->rowloss, want_argmax ? c->argmax : (int32_t *)nullptr);
-        if (train) hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(256), 0, c->s, c->rowloss, B, c->d_loss);
+                           c->rowloss, want_argmax ? c->argmax : (int32_t *)nullptr, train ? c->h_rowloss : (float *)nullptr);
+        if (train) c->loss_rows = B;
     }
     NVQA_HIP(hipGetLastError());
     return 0;
@@ -1257,7 +1334,15 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
     const int B = d.B, R = d.R, L = d.L, E = d.E, I = d.I, A = d.A, V = d.V, TS = c->TS, TB = TS * B;
     float *G = c->G;
     // only the top layer's h at step tmax receives a gradient from the head (Encoder_lstm.lua:238-239)
-    NVQA_HIP(hipMemsetAsync(c->dCT, 0, (size_t)2 * L * B * R * 4, c->s)); // dCT and dHT (one allocation)
+    // (dCT and dHT are one allocation.  The head product below rewrites dHT[L-1] in full and the persistent BPTT kernel only READS
+    // the two buffers, so on that route they stay as they were zeroed; the per-level finisher carries dc in dCT in place.)
+    {
+        int rbx = 0;
+        if (!(c->dct_zero && persist_bwd_rows(c, &rbx) != 0)) {
+            NVQA_HIP(hipMemsetAsync(c->dCT, 0, (size_t)2 * L * B * R * 4, c->s));
+            c->dct_zero = true;
+        }
+    }
     {
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 4.0 * B * A * R, (2.0 * A * R + 2.0 * B * A) * 4);
         if (ride) ride_add(c, mkargs(c->dscores, A, c->qd, R, A, R, B), EpiStore{G + c->lo.w_o, R, 0});
@@ -1323,12 +1408,12 @@ static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
         NVQA_TRY(arch2_backward(c, dr));
     }
     NVQA_TRY(batch_release(c)); // (arch2's backward pass reads the image features once more: dW_p)
+    NVQA_TRY(latch_flush(c));   // (an err latch no kernel of the step carried: before the status word is exchanged)
     NVQA_TRY(reduce_join(c));
-    c->have_grads = true;
-    NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
+    c->have_grads = true; // (the loss: k_softmax_ce wrote its rows into the pinned h_rowloss; loss_mean_host adds them when asked)
     if (loss_out) {
         NVQA_HIP(hipStreamSynchronize(c->s));
-        *loss_out = *c->h_loss;
+        *loss_out = loss_mean_host(c);
         NVQA_TRY(check_persist(c));
     }
     return 0;
@@ -1489,9 +1574,8 @@ extern "C" int nvqa_evaluate(nvqa_ctx *c, int32_t n, const int32_t *tokens, cons
     else NVQA_TRY(arch2_forward(c, dr, false, true));
     if (labels) { // mean cross-entropy of the first n rows (short batches are padded with copies of row 0)
         hipLaunchKernelGGL(k_softmax_ce, dim3((d.B + 3) / 4), dim3(256), 0, c->s, c->scores, c->lab, d.B, d.A, (float *)nullptr,
-                           c->rowloss, (int32_t *)nullptr);
-        hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(256), 0, c->s, c->rowloss, n, c->d_loss);
-        NVQA_HIP(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(float), hipMemcpyDeviceToHost, c->s));
+                           c->rowloss, (int32_t *)nullptr, c->h_rowloss);
+        c->loss_rows = n;
     }
     if (mc_ans) // reuses the dscores buffer's first n ints for the answers (training overwrites it every step)
         hipLaunchKernelGGL(k_mc_argmax, dim3((n + 3) / 4), dim3(256), 0, c->s, c->scores, c->mc, n, d.A, n_mc,
@@ -1502,7 +1586,7 @@ extern "C" int nvqa_evaluate(nvqa_ctx *c, int32_t n, const int32_t *tokens, cons
     if (scores_out) NVQA_HIP(hipMemcpy(scores_out, c->scores, (size_t)n * d.A * 4, hipMemcpyDeviceToHost));
     if (argmax_out) NVQA_HIP(hipMemcpy(argmax_out, c->argmax, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (mc_argmax_out) NVQA_HIP(hipMemcpy(mc_argmax_out, c->dscores, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (loss_out) *loss_out = *c->h_loss;
+    if (loss_out) *loss_out = loss_mean_host(c);
     return 0;
 }
 
@@ -1531,6 +1615,7 @@ extern "C" int nvqa_set_ref_quirks(nvqa_ctx *c, int flags)
     NVQA_HIP(hipMemsetAsync(c->dHT, 0, (size_t)c->d.L * BR * 4, c->s));  // the carried h0 state
     NVQA_HIP(hipMemsetAsync(c->Hs[c->d.L - 1], 0, BR * 4, c->s));        // and the step-0 rows it may have been copied into
     c->quirks = flags;
+    c->h0_img_clean = false;
     return 0;
 }
 extern "C" int nvqa_set_precision(nvqa_ctx *c, int bf16)
@@ -1553,7 +1638,7 @@ extern "C" int nvqa_get_loss(nvqa_ctx *c, float *loss_out)
     if (!c || !loss_out) { set_error("NULL argument"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     NVQA_HIP(hipStreamSynchronize(c->s));
-    *loss_out = *c->h_loss;
+    *loss_out = loss_mean_host(c);
     return check_persist(c);
 }
 
@@ -1656,11 +1741,17 @@ extern "C" int nvqa_step_indices(nvqa_ctx *c, const int64_t *qinds, const nvqa_d
         if (qinds[b] < 0 || qinds[b] >= c->ds.n_q) { set_error("qinds[%d]=%lld outside 0..%lld", b, (long long)qinds[b], (long long)c->ds.n_q - 1); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     c->batch_uniform = c->ds.uniform_len;
-    NVQA_HIP(hipMemcpyAsync(c->qinds, qinds, (size_t)d.B * 8, hipMemcpyHostToDevice, c->s));
     {
         ProfScope ps(c, PF_GATHER, 0, 2.0 * d.B * d.I * 4);
-        hipLaunchKernelGGL(k_gather_batch, dim3(d.B), dim3(256), 0, c->s, c->qinds, c->ds.Q, c->ds.QL, c->ds.IP,
-                           c->ds.ANS, c->ds.F, d.T, d.I, c->tok, c->len, c->lab, c->img);
+        if (d.B <= NVQA_QARG_MAX && c->ds.n_q <= 0x7fffffffLL) { // the ids as kernel arguments (kernels.h: no H2D blit in front of the step)
+            for (int b = 0; b < d.B; ++b) c->qarg.q[b] = (int32_t)qinds[b]; // (the launch copies it into the kernarg segment)
+            hipLaunchKernelGGL(k_gather_batch<true>, dim3(d.B), dim3(256), 0, c->s, c->qarg, (const int64_t *)nullptr, c->ds.Q, c->ds.QL, c->ds.IP,
+                               c->ds.ANS, c->ds.F, d.T, d.I, c->tok, c->len, c->lab, c->img);
+        } else {
+            NVQA_HIP(hipMemcpyAsync(c->qinds, qinds, (size_t)d.B * 8, hipMemcpyHostToDevice, c->s));
+            hipLaunchKernelGGL(k_gather_batch<false>, dim3(d.B), dim3(256), 0, c->s, QIdxArg{}, c->qinds, c->ds.Q, c->ds.QL, c->ds.IP,
+                               c->ds.ANS, c->ds.F, d.T, d.I, c->tok, c->len, c->lab, c->img);
+        }
     }
     NVQA_HIP(hipGetLastError());
     return run_step(c, dropout, loss_out);

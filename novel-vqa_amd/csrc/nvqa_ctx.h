@@ -53,6 +53,20 @@ enum ProfId {
     PF_COUNT
 };
 
+// sample ids of nvqa_step_indices as kernel arguments of k_gather_batch (kernels.h)
+#define NVQA_QARG_MAX 768
+struct QIdxArg { int32_t q[NVQA_QARG_MAX]; };
+
+// The err record of a persistent launch is latched (copied to the sticky record and the host, its counter block zeroed) by an
+// extra workgroup of a kernel that runs later in the step anyway, not by a launch of its own (persist_fwd.hip).
+struct LatchArgs {
+    unsigned *cnt = nullptr; // nullptr: nothing to latch
+    unsigned words = 0;
+    unsigned *sticky = nullptr;
+    float *dp_status = nullptr;
+    unsigned *host_copy = nullptr;
+};
+
 struct ProfEntry {
     double ms = 0, flops = 0, bytes = 0;
     int64_t launches = 0;
@@ -111,6 +125,8 @@ struct nvqa_ctx {
     int32_t *tok = nullptr, *len = nullptr, *lab = nullptr;
     float *img = nullptr;
     int64_t *qinds = nullptr;
+    nvqa::QIdxArg qarg;                      // this step's sample ids on their way into the kernarg segment
+    nvqa::LatchArgs latch_pending[2];        // err latches of this step's persistent launches (0 forward, 1 BPTT) waiting for a carrier
     int32_t *sort_idx = nullptr, *sort_inv = nullptr, *nrows = nullptr, *ptok = nullptr;
     int32_t *tinfo = nullptr; // arch2: {tmax, tmax-1}
 
@@ -121,8 +137,10 @@ struct nvqa_ctx {
     float *Cs[NVQA_MAX_LAYERS] = {};           // [(TS+1)*B][R]
     float *U[NVQA_MAX_LAYERS] = {};            // [TS*B][R] Dropout(h of layer below), l >= 1
     float *dCT = nullptr, *dHT = nullptr;      // [L][B][R] head -> final state gradients
+    bool dct_zero = false;                     // arch2: dCT and dHT[0 .. L-2] are known to be zero (nobody wrote them since the last clear)
+    bool h0_img_clean = false;                 // bf16: the step-0 slices of the bf16 images of Hs hold what Hs' step-0 slices hold (zeros)
     float *qd = nullptr, *vd = nullptr, *qc = nullptr, *ic = nullptr, *zd = nullptr;
-    float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr, *d_loss = nullptr;
+    float *scores = nullptr, *dscores = nullptr, *rowloss = nullptr;
     float *dqc = nullptr, *dic = nullptr;
     float *colpart = nullptr, *slabs = nullptr;
     float *chain_slabs = nullptr; // [L][2][NVQA_BWD_Z][B][R] split-K partials of the BPTT level products
@@ -137,9 +155,14 @@ struct nvqa_ctx {
     bool img_fwd_valid = false, img_bwd_valid = false; // this step's persistent bf16 kernels wrote act_b16 / dg_b16
     bool wgrad_tr = true;              // bf16 weight gradients on the transposed-read kernel (wgrad_bf16.h)
     float *pb_bias = nullptr;     // [L][RB][4R] LSTM bias-gradient partial sums left by the persistent BPTT kernel
+    unsigned *pb_bias_cnt = nullptr; // [L][32] arrivals per (layer, unit tile): the last row block's workgroup writes the bias gradients (NVQA_BIAS_IN_BPTT=0: k_bias_sum)
+    bool pb_bias_done = false;    // this step's persistent BPTT launch wrote b_i2h / b_h2h of every layer itself
     int pb_bias_rb = 0;           // row blocks of this step's partial sums (0: none: lstm_wgrads runs the column-sum kernels)
+    bool wi2h0_img_step = false;         // ... made by this step's embedding launch (else lstm_dx0 makes it)
     unsigned short *wi2h0_t16 = nullptr; // bf16 image of W_i2h[0]^T ([E][4R]) for the gfx950-form d(input) product, remade every step
     unsigned short *dg_b16 = nullptr;  // bf16 image of dG for the persistent BPTT kernel's bf16 instance (lstm_persist_bwd2.h)
+    unsigned short *x0_b16 = nullptr;  // bf16 image of X0 ([TS*B][E]), written by the embedding kernels in bf16 mode (E % 8 == 0)
+    bool x0_img_valid = false;         // ... for the current step
     unsigned short *act_b16 = nullptr; // bf16 images of Hs / U for the persistent kernel's bf16 instance (lstm_persist.h)
     unsigned *h_pf_err = nullptr; // pinned copies of the sticky err records (forward: words 0-3, BPTT: words 4-7)
     unsigned pf_spin = 0;         // NVQA_PF_SPIN at nvqa_create: polls before a persistent-kernel wait gives up (0: NVQA_PF_SPIN_LIMIT)
@@ -153,7 +176,8 @@ struct nvqa_ctx {
     size_t slab_floats = 0;
     int32_t *argmax = nullptr;
     int32_t *mc = nullptr;   // multiple-choice candidates of the batch being evaluated (nvqa_evaluate), allocated on first use
-    float *h_loss = nullptr; // pinned
+    float *h_rowloss = nullptr; // pinned [B]: the row losses of the last step / evaluation, written by k_softmax_ce itself
+    int loss_rows = 0;          // rows of h_rowloss the loss is the mean of (B after a training step, n after nvqa_evaluate)
     double *norm_part = nullptr; // nvqa_param_norms: per-workgroup sums of squares, allocated on first use
 
     nvqa::Dataset ds;

@@ -117,6 +117,11 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         a.dr = dr; a.spin_limit = lim; a.dbg = dbg;
         a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec; a.err = err;
         a.bias_part = c->pb_bias;
+        if (c->pb_bias && c->pb_bias_cnt) { // the kernel's last workgroup per (layer, unit tile) writes the bias gradients itself
+            a.bias_cnt = c->pb_bias_cnt;
+            for (int l = 0; l < L; ++l) { a.bias_i[l] = c->G + c->lo.b_i2h[l]; a.bias_h[l] = c->G + c->lo.b_h2h[l]; }
+            c->pb_bias_done = true;
+        }
         a.ts = c->pf_ts + 1024;
         if (take_jobs) {
             c->ride.has_tok = c->tok_job_pending ? 1 : 0;

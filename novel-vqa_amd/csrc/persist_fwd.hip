@@ -4,34 +4,43 @@
 
 #include "lstm_persist.h"
 #include "persist_host.h"
+#include "latch.h"
 
 namespace nvqa {
 
-// The err record of a launch lives in the last 16 bytes of its counter block.  Each launch is followed by this latch, which
+// The err record of a launch lives in the last 16 bytes of its counter block.  Each launch is followed by a latch, which
 // (1) copies the FIRST failure into a sticky record that only the host clears, once it has reported it (check_persist;
 // k_rmsprop refuses to apply gradients while a record is set; dp_status[0] (data parallel) is summed over the ranks at the
 // end of the step, so that every rank skips the update if any rank's kernel gave up), (2) writes the sticky record
 // straight into the host's pinned copy (a 16-byte D2H copy is a 5 us blit kernel of its own), and (3) ZEROES the counter
 // block for the next launch (the memset in front of every launch was another 5 us fill kernel).  The blocks are zeroed
-// once at creation.
-__global__ void k_err_latch(unsigned *cnt, unsigned words, unsigned *sticky, float *dp_status, unsigned *host_copy)
-{
-    if (threadIdx.x == 0) {
-        const unsigned *err = cnt + words - 4;
-        if (err[0] != 0) {
-            if (sticky[0] == 0) { sticky[1] = err[1]; sticky[2] = err[2]; sticky[3] = err[3]; sticky[0] = err[0]; }
-            if (dp_status) dp_status[0] = 1.0f;
-        }
-        for (int i = 0; i < 4; ++i) __hip_atomic_store(host_copy + i, sticky[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < words; i += blockDim.x) cnt[i] = 0;
-}
+// once at creation.  Round 4: the latch is no longer a launch of its own (2 x 5 us per step at the launch floor) -- it is
+// the LAST workgroup of a kernel that follows the persistent launch anyway (kernels.h: err_latch_block, carried by
+// k_head_prep / k_arch2_head_prep behind the forward launch and by k_emb_bwd_tok behind the BPTT launch); where no
+// carrier comes (forward-only entry points on a fallback route, ...) latch_flush launches k_err_latch.
+__global__ void k_err_latch(LatchArgs a) { err_latch_block(a); }
+
 int persist_latch_err(nvqa_ctx *c, unsigned *cnt, size_t words, int off)
 {
-    hipLaunchKernelGGL(k_err_latch, dim3(1), dim3(1024), 0, c->s, cnt, (unsigned)words, c->pf_sticky + off,
-                       c->comm ? c->dp_status : (float *)nullptr, c->h_pf_err + off);
-    NVQA_HIP(hipGetLastError());
+    LatchArgs &l = c->latch_pending[off / 4];
+    if (l.cnt) NVQA_TRY(latch_flush(c)); // (an older record still waiting for a carrier: latch it now)
+    l.cnt = cnt; l.words = (unsigned)words; l.sticky = c->pf_sticky + off;
+    l.dp_status = c->comm ? c->dp_status : nullptr; l.host_copy = c->h_pf_err + off;
+    return 0;
+}
+LatchArgs latch_take(nvqa_ctx *c, int which)
+{
+    const LatchArgs l = c->latch_pending[which];
+    c->latch_pending[which] = LatchArgs{};
+    return l;
+}
+int latch_flush(nvqa_ctx *c)
+{
+    for (int w = 0; w < 2; ++w) {
+        if (!c->latch_pending[w].cnt) continue;
+        hipLaunchKernelGGL(k_err_latch, dim3(1), dim3(256), 0, c->s, latch_take(c, w));
+        NVQA_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -101,8 +110,15 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
         const size_t hs = (size_t)(TS + 1) * B * R, us = (size_t)TS * B * R;
         if (!c->act_b16) NVQA_HIP(hipMalloc((void **)&c->act_b16, (size_t)L * (hs + us) * 2));
         for (int l = 0; l < L; ++l) { a.Hb[l] = c->act_b16 + l * hs; a.Ub[l] = c->act_b16 + L * hs + l * us; }
-        hipLaunchKernelGGL(k_h0_image, dim3((B * R / 2 + 255) / 256, L), dim3(256), 0, c->s, c->Hs[0], a.Hb[0], hs, B * R);
-        NVQA_HIP(hipGetLastError());
+        // layer 0's input segment from the bf16 image of X0 the embedding kernel left (E = R: the same instance as the layers above)
+        a.Ub[0] = d.E == R && c->x0_img_valid ? c->x0_b16 : nullptr;
+        // step-0 slices of the images: zeros like Hs' own (written once), or the carried h0 of NVQA_QUIRK_H0 (every step)
+        const bool carried = d.arch == NVQA_ARCH2 && (c->quirks & NVQA_QUIRK_H0);
+        if (carried || !c->h0_img_clean) {
+            hipLaunchKernelGGL(k_h0_image, dim3((B * R / 2 + 255) / 256, L), dim3(256), 0, c->s, c->Hs[0], c->act_b16, hs, B * R);
+            NVQA_HIP(hipGetLastError());
+            c->h0_img_clean = !carried;
+        }
     }
     for (int l = 0; l < L; ++l) {
         a.Wi[l] = c->P + c->lo.w_i2h[l]; a.Wh[l] = c->P + c->lo.w_h2h[l];

@@ -15,7 +15,9 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT);
 // bf16 + NVQA_QUIRK_H0: refresh the bf16 image of the top layer's step-0 hidden state after arch2_backward rewrote it
 int persist_reimage_h0_top(nvqa_ctx *c);
 // copies a launch's err record (device) into the sticky record at word `off` (0 forward, 4 BPTT) and that to the host
-int persist_latch_err(nvqa_ctx *c, unsigned *cnt, size_t words, int off); // after every persistent launch: latch the err record, zero the counter block
+int persist_latch_err(nvqa_ctx *c, unsigned *cnt, size_t words, int off); // after every persistent launch: its err latch now waits for a carrier kernel
+LatchArgs latch_take(nvqa_ctx *c, int which); // a kernel that follows the launch (0 forward, 1 BPTT) carries the latch as an extra workgroup ...
+int latch_flush(nvqa_ctx *c);                 // ... or, where none does, k_err_latch runs it alone
 
 // BPTT as one launch: row tiles per workgroup (0: not eligible / switched off), row blocks in *RB
 int persist_bwd_rows(const nvqa_ctx *c, int *RB);

@@ -91,4 +91,22 @@ def test_create_failure_frees_the_context_and_bounds_are_checked(pkg, orc, monke
     with pytest.raises(pkg.binding.NvqaError, match="arch2: T="):
         pkg.binding.Context(gdims(pkg, orc.make_dims(arch=2, B=4, T=300, V=9, E=8, R=8, L=1, I=8, C=4, A=4)), 0)
     with pytest.raises(pkg.binding.NvqaError, match="k_sort_lengths"):
-        pkg.binding.Context(gdims(pkg, orc.make_dims(arch=1, B=20000, T=6, V=9, E=8, R=8, L=1, I=8, C=8, A=4)), 0)
+        pkg.binding.Context(gdims(pkg, orc.make_dims(arch=1, B=8, T=1000, V=9, E=8, R=8, L=1, I=8, C=8, A=4)), 0)
+
+
+def test_length_sort_of_a_batch_larger_than_its_workgroup(pkg, orc):
+    """k_sort_lengths is one workgroup of 1024 threads; a batch of 2100 rows takes three passes, and the stable rank of a row
+    (rows of its length in earlier passes + in earlier waves of its pass + in lower lanes of its wave) must still give the
+    order of sort_encoding_onehot_right_align (misc/RNNUtils.lua:84-103): a full step against the oracle, ragged lengths."""
+    from util import assert_grads
+    d = orc.make_dims(arch=1, B=2100, T=9, V=50, E=16, R=16, L=2, I=32, C=24, A=12)
+    params = orc.synth_params(d)
+    tok, lens, img, lab = orc.synth_batch(d, seed=8, full_length=False, min_len=1)
+    dr = orc.Dropout(1, 0.5, 123, 5)
+    ref = orc.Oracle(np.float64).step(d, params, tok, lens, img, lab, dr)
+    ctx = pkg.binding.Context(gdims(pkg, d), 0)
+    ctx.set_params(params)
+    loss = ctx.step(tok, lens, img, lab, gdrop(pkg, dr))
+    assert abs(loss - ref["loss"]) <= 2e-6 * abs(ref["loss"])
+    assert_grads(orc, d, ctx.get_grads(), ref["grads"], 2e-5, "sort_three_passes")
+    ctx.close()

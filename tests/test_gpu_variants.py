@@ -157,7 +157,7 @@ def test_evaluate_validation_loss_and_multiple_choice(pkg, orc):
 @pytest.mark.parametrize("arch", [1, 2])
 def test_embedding_gradient_skewed_vocabulary(pkg, orc, arch):
     """Real questions are Zipfian ("what", "is", "the" in most of them; arch2's START token in every row): the embedding /
-    lookup gradient by token segments (kernels.h: k_tok_index + k_emb_bwd_seg) with words that occur once, a few dozen
+    lookup gradient by token segments (kernels.h: k_tok_index + k_emb_bwd_tok) with words that occur once, a few dozen
     times (one wave), several hundred times and more than B times (chunked over waves, combined by the last to arrive)
     against the f64 oracle; bit-reproducible; and the same values as the scanning kernel (NVQA_EMB_SEG=0) to f32
     summation-order noise."""
