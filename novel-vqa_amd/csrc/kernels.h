@@ -199,11 +199,25 @@ __global__ void k_sort_lengths(const int32_t *len, int B, int T, int32_t *sort_i
 // ---------------------------------------------------------------------------------
 __global__ void k_emb_fwd(const int32_t *tok, const int32_t *sort_idx, const int32_t *nrows,
                           const float *WeT, const float *be, int B, int T, int E, Drop dr,
-                          float *X, int32_t *ptok, unsigned short *Xb /* bf16 image of X, or NULL */, TransposeJob tj)
+                          float *X, int32_t *ptok, unsigned short *Xb /* bf16 image of X, or NULL */, TransposeJob tj,
+                          const float *img, float *vd, int I, int vd_first_block)
 {
     if (tj.W && (int)blockIdx.x >= tj.first_block) {
         __shared__ float tt[32][33];
         transpose_to_bf16_block(tj, blockIdx.x - tj.first_block, tt);
+        return;
+    }
+    if (vd && (int)blockIdx.x >= vd_first_block) {
+        // Dropout on the image feature (netdef.lua:11), row b = blockIdx.x - vd_first_block: k_head_prep's second half, done here --
+        // before the LSTM -- when the image projection rides in the persistent forward launch (lstm_persist.h) and needs it early
+        const int b = blockIdx.x - vd_first_block;
+        for (int j = 4 * threadIdx.x; j < I; j += 4 * blockDim.x) {
+            const uint64_t idx = (uint64_t)b * I + j;
+            const float4 v = *reinterpret_cast<const float4 *>(img + idx);
+            *reinterpret_cast<float4 *>(vd + idx) =
+                make_float4(dr.scale(NVQA_SITE_V, idx) * v.x, dr.scale(NVQA_SITE_V, idx + 1) * v.y,
+                            dr.scale(NVQA_SITE_V, idx + 2) * v.z, dr.scale(NVQA_SITE_V, idx + 3) * v.w);
+        }
         return;
     }
     const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
@@ -260,6 +274,7 @@ __global__ void k_head_prep(const float *Cfin /*[L][B][R]*/, const float *Hfin, 
             make_float4(dr.scale(NVQA_SITE_Q, idx) * v.x, dr.scale(NVQA_SITE_Q, idx + 1) * v.y,
                         dr.scale(NVQA_SITE_Q, idx + 2) * v.z, dr.scale(NVQA_SITE_Q, idx + 3) * v.w);
     }
+    if (!vd) return; // (made by the embedding launch already: the image projection rode in the forward launch)
     for (int j = 4 * threadIdx.x; j < I; j += 4 * blockDim.x) {
         const uint64_t idx = (uint64_t)b * I + j;
         const float4 v = *reinterpret_cast<const float4 *>(img + idx);
@@ -281,11 +296,25 @@ __global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, 
     const int lane = threadIdx.x & 63;
     if (b >= B) return;
     const float *s = scores + (size_t)b * A;
+    // The row lives in registers (up to 16 values per lane: A <= 1024, the reference's 1000 answers): one read of the
+    // scores instead of three dependent passes over them.  Same arithmetic in the same order as the general loops below
+    // (per-lane strided partial sums, then the wave butterfly): bit-identical.
+    constexpr int RV = 16;
+    const bool small = A <= 64 * RV;
+    float rv[RV];
     float mx = -INFINITY;
     int am = 0x7fffffff;
-    for (int a = lane; a < A; a += 64) {
-        const float v = s[a];
-        if (v > mx) { mx = v; am = a; }
+    if (small) {
+#pragma unroll
+        for (int j = 0; j < RV; ++j) rv[j] = lane + 64 * j < A ? s[lane + 64 * j] : -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RV; ++j)
+            if (rv[j] > mx) { mx = rv[j]; am = lane + 64 * j; }
+    } else {
+        for (int a = lane; a < A; a += 64) {
+            const float v = s[a];
+            if (v > mx) { mx = v; am = a; }
+        }
     }
     const float wmx = wave_max(mx);
     if (argmax) {
@@ -296,7 +325,13 @@ __global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, 
     }
     if (!labels) return;
     float sum = 0.f;
-    for (int a = lane; a < A; a += 64) sum += expf(s[a] - wmx);
+    if (small) {
+#pragma unroll
+        for (int j = 0; j < RV; ++j)
+            if (lane + 64 * j < A) sum += expf(rv[j] - wmx);
+    } else {
+        for (int a = lane; a < A; a += 64) sum += expf(s[a] - wmx);
+    }
     sum = wave_sum(sum);
     const float lse = wmx + logf(sum);
     const int y = labels[b] - 1;
@@ -310,8 +345,16 @@ __global__ void k_softmax_ce(const float *scores, const int32_t *labels, int B, 
     }
     if (dscores) {
         const float invB = 1.0f / (float)B;
-        for (int a = lane; a < A; a += 64)
-            dscores[(size_t)b * A + a] = (expf(s[a] - lse) - (a == y ? 1.0f : 0.0f)) * invB;
+        if (small) {
+#pragma unroll
+            for (int j = 0; j < RV; ++j) {
+                const int a = lane + 64 * j;
+                if (a < A) dscores[(size_t)b * A + a] = (expf(rv[j] - lse) - (a == y ? 1.0f : 0.0f)) * invB;
+            }
+        } else {
+            for (int a = lane; a < A; a += 64)
+                dscores[(size_t)b * A + a] = (expf(s[a] - lse) - (a == y ? 1.0f : 0.0f)) * invB;
+        }
     }
 }
 
@@ -638,8 +681,17 @@ __global__ void k_arch2_tmax(const int32_t *tok, int B, int T, int32_t *nrows /*
     __shared__ int colany[NVQA_ARCH2_TMAX]; // T <= NVQA_ARCH2_TMAX is checked by nvqa_create
     for (int t = threadIdx.x; t < T; t += blockDim.x) colany[t] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < B * T; i += blockDim.x)
-        if (tok[i] != 0) colany[i % T] = 1; // benign race: every writer stores 1
+    // (eight loads in flight per thread: the one-at-a-time loop made this one-workgroup kernel a chain of B T / 1024 global
+    // round trips -- 8 us for the bench shape)
+    const int n = B * T, stride = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * stride) {
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = i0 + j * stride < n ? tok[i0 + j * stride] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v[j] != 0) colany[(i0 + j * stride) % T] = 1; // benign race: every writer stores 1
+    }
     for (int b = threadIdx.x; b < B; b += blockDim.x) { sort_idx[b] = b; sort_inv[b] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -714,13 +766,18 @@ __global__ void k_arch2_head_prep(const float *Htop /*[(TS+1)*B][R]*/, const int
 // M = B projections W_q Dropout(q), W_v Dropout(v) run as ONE split-K multi-problem launch into
 // slabs (each alone has only 128 tiles); here: slab sums + bias, tanh, qc (*) ic, Dropout.
 // ---------------------------------------------------------------------------------
-__global__ void k_head_fuse(const float *sq, const float *sv, int Z, size_t n, int C, const float *bq,
+__global__ void k_head_fuse(const float *sq, const float *sv, int Z, int Zv, size_t n, int C, const float *bq,
                             const float *bv, Drop dr, float *qc, float *ic, float *zd, int askip)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float a = 0.f, b = 0.f;
-    for (int z = 0; z < Z; ++z) { a += sq[(size_t)z * n + i]; b += sv[(size_t)z * n + i]; }
+    if (Zv == Z) {
+        for (int z = 0; z < Z; ++z) { a += sq[(size_t)z * n + i]; b += sv[(size_t)z * n + i]; }
+    } else { // the image projection came whole from the forward launch's riding workgroups (Zv = 1)
+        for (int z = 0; z < Z; ++z) a += sq[(size_t)z * n + i];
+        for (int z = 0; z < Zv; ++z) b += sv[(size_t)z * n + i];
+    }
     const int c = (int)(i % C);
     const float q = tanhf_(a + bq[c]), v = tanhf_(b + bv[c]);
     qc[i] = q;
@@ -807,8 +864,12 @@ __global__ void k_bias_sum(const float *part /*[RB][N]*/, int RB, int N, float *
 // failed step at its next synchronisation point -- h_dp[1] (pinned) keeps the count of the LAST failed step until the host
 // clears it, so a later good step does not hide the report on the ranks whose own kernels were fine.
 __global__ void k_rmsprop(float4 *x, const float4 *g, float4 *m, size_t n4, float lr, float alpha,
-                          float eps, float wd, float clamp, float gscale, const unsigned *skip, const float *dp_skip, float *h_dp)
+                          float eps, float wd, float clamp, float gscale, const unsigned *skip, const float *dp_skip, float *h_dp,
+                          float *dp_next)
 {
+    // (data parallel: the status word the NEXT step will use is cleared here -- the two words alternate -- instead of by a 5 us
+    // fill kernel at the head of every step)
+    if (dp_next && blockIdx.x == 0 && threadIdx.x == 0) *dp_next = 0.f;
     if (skip && (skip[0] | skip[4]) != 0u) return;
     if (dp_skip && dp_skip[0] != 0.f) {
         if (h_dp && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(h_dp + 1, dp_skip[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -25,6 +25,7 @@
 // Results are bit-reproducible run to run (fixed K order per output) but the K order differs from the per-level
 // kernels of gemm_f32.h (f32 rounding only).
 #pragma once
+#include "ride_jobs.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -57,6 +58,12 @@ struct PersistFwdArgs {
     unsigned long long *ts; // dbg & 32: per workgroup {start, weights resident, steps done} in 100 MHz ticks (tools/pfdbg.sh)
     int h0_top;    // arch2 NVQA_QUIRK_H0: the top layer's h_{-1} (slice 0 of Hs) is live at step 0
     Drop dr;
+    // f32 instances: a product for the layer-0 workgroups to multiply AFTER their last step (fr_on).  Layer 0 has 70 % of
+    // layer 1's work per step (K = E + R against 2R) and nothing waits for it, so its workgroups are done ~0.28 ms before
+    // the launch ends; arch1's image projection W_v Dropout(v) of the head (4.3 GFLOP, independent of the LSTM) is 128
+    // tiles of 64 x 64 x 4096 for them -- off the step's critical path instead of 40 us on it (nvqa_api.hip: arch1_forward).
+    RideGemm fr;   // A_KC x B_KC, full K per tile, EpiStore
+    int fr_on;
 };
 
 // hardware exp2 / reciprocal forms of the gate non-linearities (v_exp_f32, v_rcp_f32: 1 ulp each): absolute error
@@ -606,6 +613,16 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_fwd_persist(Persist
     } else {
         if (l == 0) persist_fwd_layer<G0A, GR, MT, BF, false, RAG>(a, l, rb, ut, pf_smem);
         else persist_fwd_layer<GR, GR, MT, BF, BF, RAG>(a, l, rb, ut, pf_smem);
+    }
+    if constexpr (!BF) {
+        if (l == 0 && a.fr_on) { // the riding product (PersistFwdArgs::fr): tiles dealt round-robin to the layer-0 workgroups
+            __syncthreads();
+            const int me = ut * a.RB + rb, n = a.RB * a.NU, tx = a.fr.tx, total = tx * a.fr.ty;
+            for (int t = me; t < total; t += n) {
+                gemm_f32_body<CfgRide, A_KC, B_KC, false, EpiStore, 0, true>(a.fr.g, a.fr.e, t % tx, t / tx, 0, pf_smem);
+                __syncthreads();
+            }
+        }
     }
     if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4 + 2] = wall_clock64();
 }

@@ -316,6 +316,7 @@ static int create_impl(nvqa_ctx *c)
         c->persist_on = !(ep && ep[0] == '0');
         { const char *e = getenv("NVQA_RIDE_GEMM"); c->ride_gemm_on = !(e && e[0] == '0'); }   // A/B switches of the ride-along jobs,
         { const char *e = getenv("NVQA_TOK_IN_BPTT"); c->tok_in_bptt_on = !(e && e[0] == '0'); } // read here like the other switches
+        { const char *e = getenv("NVQA_RIDE_FWD"); c->ride_fwd_on = !(e && e[0] == '0'); }
         hipDeviceProp_t prop;
         NVQA_HIP(hipGetDeviceProperties(&prop, c->device));
         c->num_cus = prop.multiProcessorCount;
@@ -1115,6 +1116,11 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     const nvqa_dims &d = c->d;
     const int B = d.B, T = d.T, R = d.R, L = d.L, E = d.E, I = d.I, C = d.C, A = d.A, Q = 2 * R * L;
     const int TB = T * B;
+    const int Zh = 4;                 // K slices of the head's projections
+    const size_t nBC = (size_t)B * C;
+    // f32, persistent forward launch ahead: the image projection W_v Dropout(v) rides in that launch's layer-0 workgroups, which
+    // are done ~30 % before it ends (lstm_persist.h: PersistFwdArgs::fr).  NVQA_RIDE_FWD=0: in the head's own launch.
+    const bool fr = c->ride_fwd_on && !c->bf16 && persist_rows(c) > 0 && Q % (32 * Zh) == 0 && I % 64 == 0 && (Zh + 1) * nBC <= c->slab_floats;
     {
         ProfScope ps(c, PF_ASSEMBLE);
         hipLaunchKernelGGL(k_sort_lengths, dim3(1), dim3(1024), (3 + 16) * (T + 1) * sizeof(int), c->s, c->len, B, T,
@@ -1123,28 +1129,46 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
     {
         ProfScope ps(c, PF_EMB_FWD, 0, 2.0 * TB * E * 4);
         NVQA_TRY(x0_image_begin(c, TB));
+        const int rows_blocks = (TB + 3) / 4, vd_blocks = fr ? B : 0;
         TransposeJob tj;
-        NVQA_TRY(wi2h0_image_job(c, train, (TB + 3) / 4, &tj));
-        hipLaunchKernelGGL(k_emb_fwd, dim3((TB + 3) / 4 + tj.nblocks), dim3(256), 0, c->s, c->tok, c->sort_idx, c->nrows,
-                           c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok, c->x0_img_valid ? c->x0_b16 : nullptr, tj);
+        NVQA_TRY(wi2h0_image_job(c, train, rows_blocks + vd_blocks, &tj));
+        hipLaunchKernelGGL(k_emb_fwd, dim3(rows_blocks + vd_blocks + tj.nblocks), dim3(256), 0, c->s, c->tok, c->sort_idx, c->nrows,
+                           c->P + c->lo.w_e, c->P + c->lo.b_e, B, T, E, dr, c->X0, c->ptok, c->x0_img_valid ? c->x0_b16 : nullptr, tj,
+                           c->img, fr ? c->vd : (float *)nullptr, I, rows_blocks);
+    }
+    if (fr) { // sv = Dropout(v) W_v^T, whole K per 64 x 64 tile, into the slab the finisher reads (k_head_fuse: Zv = 1)
+        RideGemm &r = c->fwd_ride;
+        r.g = mkargs(c->vd, I, c->P + c->lo.w_v, I, B, C, I);
+        r.e = EpiStore{c->slabs + Zh * nBC, C, nBC};
+        r.tx = (C + CfgRide::BN - 1) / CfgRide::BN; r.ty = (B + CfgRide::BM - 1) / CfgRide::BM;
+        c->fwd_ride_pending = true;
     }
     NVQA_HIP(hipGetLastError());
     NVQA_TRY(lstm_forward(c, dr));
+    c->fwd_ride_pending = false;
+    const bool fr_done = fr && c->fwd_ride_done; // (fr without fr_done: the forward took another route after all; Dropout(v) exists either way)
     if (train) NVQA_TRY(emb_index_begin(c, d.V, TB));
     {
-        ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * (Q + I) * 4);
+        ProfScope ps(c, PF_HEAD_PREP, 0, 2.0 * B * (Q + (fr ? 0 : I)) * 4);
         const LatchArgs la = latch_take(c, 0); // the forward launch's err latch rides as an extra workgroup (latch.h)
         hipLaunchKernelGGL(k_head_prep, dim3(B + (la.cnt ? 1 : 0)), dim3(256), 0, c->s, c->Cs[0] + (size_t)T * B * R,
-                           c->Hs[0] + (size_t)T * B * R, (size_t)(T + 1) * B * R, c->sort_inv, c->img, B, R, L, I, dr, c->qd, c->vd, la);
+                           c->Hs[0] + (size_t)T * B * R, (size_t)(T + 1) * B * R, c->sort_inv, c->img, B, R, L, I, dr, c->qd, fr ? (float *)nullptr : c->vd, la);
     }
     NVQA_HIP(hipGetLastError());
     {
-        ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * ((double)C * Q + (double)C * I + (double)A * C),
+        ProfScope ps(c, PF_GEMM_HEAD_FWD, 2.0 * B * ((double)C * Q + (fr_done ? 0.0 : (double)C * I) + (double)A * C),
                      ((double)C * Q + (double)C * I + (double)A * C) * 4);
         // qc = tanh(W_q Dropout(q) + b_q), ic = tanh(W_v Dropout(v) + b_v), zd = Dropout(qc (*) ic):
         // both projections as one split-K multi-problem launch into slabs, then k_head_fuse
-        const int Zh = 4;
-        const size_t nBC = (size_t)B * C;
+        if (fr_done) { // the image projection came from the forward launch (one slab): only the question projection is left
+            MultiArgs<EpiStore> ma;
+            ma.g[0] = mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q, Q / Zh);
+            ma.e[0] = EpiStore{c->slabs, C, nBC};
+            ma.zsplit = Zh;
+            NVQA_HIP((launch_gemm_multi<CfgMedMulti, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 1)));
+            hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
+                               c->slabs + Zh * nBC, Zh, 1, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
+        } else
         if (Q % (32 * Zh) == 0 && I % (32 * Zh) == 0 && 2 * Zh * nBC <= c->slab_floats) {
             MultiArgs<EpiStore> ma;
             ma.g[0] = mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q, Q / Zh);
@@ -1155,7 +1179,7 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
             if (c->bf16) NVQA_HIP((launch_gemm_multi<WithBF<CfgMedMulti>::type, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             else NVQA_HIP((launch_gemm_multi<CfgMedMulti, A_KC, B_KC, false, EpiStore, 0>(c->s, ma, 2)));
             hipLaunchKernelGGL(k_head_fuse, dim3((unsigned)((nBC + 255) / 256)), dim3(256), 0, c->s, c->slabs,
-                               c->slabs + Zh * nBC, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
+                               c->slabs + Zh * nBC, Zh, Zh, nBC, C, c->P + c->lo.b_q, c->P + c->lo.b_v, dr, c->qc, c->ic, c->zd, c->fusion_askip);
         } else {
             NVQA_TRY((gemm_med<A_KC, B_KC>(c, mkargs(c->qd, Q, c->P + c->lo.w_q, Q, B, C, Q),
                                            EpiBiasTanh{c->qc, C, c->P + c->lo.b_q})));
@@ -1399,7 +1423,11 @@ static int run_step(nvqa_ctx *c, const nvqa_dropout *dropout, float *loss_out)
     const Drop dr = mkdrop(dropout, true);
     if (c->pf_spin_steps == 0) c->pf_spin = 0; // (NVQA_PF_SPIN_STEPS: back to the kernels' own limit)
     if (c->pf_spin_steps > 0) --c->pf_spin_steps;
-    if (c->comm) NVQA_HIP(hipMemsetAsync(c->dp_status, 0, 16, c->s));
+    if (c->comm) { // this step's status word: the other one than the last step's; cleared by that step's k_rmsprop (else: here)
+        c->dp_slot ^= 1;
+        if (!c->dp_clean[c->dp_slot]) NVQA_HIP(hipMemsetAsync(c->dp_status + c->dp_slot, 0, 4, c->s));
+        c->dp_clean[c->dp_slot] = false;
+    }
     if (c->d.arch == NVQA_ARCH1) {
         NVQA_TRY(arch1_forward(c, dr, true, false));
         NVQA_TRY(arch1_backward(c, dr));
@@ -1654,7 +1682,8 @@ extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps
         hipLaunchKernelGGL(k_rmsprop, dim3(2048), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P),
                            reinterpret_cast<const float4 *>(c->G), reinterpret_cast<float4 *>(c->M2), n4, lr, alpha,
                            eps, wd, clamp, inv_world * c->gscale[0], c->comm ? (const unsigned *)nullptr : c->pf_sticky,
-                           c->comm ? c->dp_status : (const float *)nullptr, c->comm ? c->h_dp_status : (float *)nullptr);
+                           c->comm ? c->dp_status + c->dp_slot : (const float *)nullptr, c->comm ? c->h_dp_status : (float *)nullptr,
+                           c->comm ? c->dp_status + (c->dp_slot ^ 1) : (float *)nullptr);
     } else { // -lr_scale of 003_train_ae_based_wp.lua:344: encoder / embedding gradients scaled before the clamp
         size_t off = 0;
         for (int sgm = 0; sgm < 3; ++sgm) {
@@ -1662,11 +1691,13 @@ extern "C" int nvqa_rmsprop_update(nvqa_ctx *c, float lr, float alpha, float eps
             hipLaunchKernelGGL(k_rmsprop, dim3(1024), dim3(256), 0, c->s, reinterpret_cast<float4 *>(c->P + off),
                                reinterpret_cast<const float4 *>(c->G + off), reinterpret_cast<float4 *>(c->M2 + off), n4,
                                lr, alpha, eps, wd, clamp, inv_world * c->gscale[sgm], c->comm ? (const unsigned *)nullptr : c->pf_sticky,
-                               c->comm ? c->dp_status : (const float *)nullptr, c->comm ? c->h_dp_status : (float *)nullptr);
+                               c->comm ? c->dp_status + c->dp_slot : (const float *)nullptr, c->comm ? c->h_dp_status : (float *)nullptr,
+                           c->comm ? c->dp_status + (c->dp_slot ^ 1) : (float *)nullptr);
             off += c->lo.seg[sgm];
         }
     }
     NVQA_HIP(hipGetLastError());
+    if (c->comm) c->dp_clean[c->dp_slot ^ 1] = true;
     return 0;
 }
 
@@ -1962,9 +1993,9 @@ static int reduce_join(nvqa_ctx *c)
         NVQA_HIP(hipEventRecord(c->evSeg[0], c->s));
         NVQA_HIP(hipStreamWaitEvent(c->sc, c->evSeg[0], 0));
         const Rccl *r = rccl_of(c);
-        const int rc = r->AllReduce(c->dp_status, c->dp_status, 4, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
+        const int rc = r->AllReduce(c->dp_status + c->dp_slot, c->dp_status + c->dp_slot, 1, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->sc);
         if (rc) { set_error("ncclAllReduce (status): %s", r->GetErrorString ? r->GetErrorString(rc) : "?"); return -1; }
-        NVQA_HIP(hipMemcpyAsync(c->h_dp_status, c->dp_status, 4, hipMemcpyDeviceToHost, c->sc)); // word 0 only: word 1 of the host copy is k_rmsprop's sticky count
+        NVQA_HIP(hipMemcpyAsync(c->h_dp_status, c->dp_status + c->dp_slot, 4, hipMemcpyDeviceToHost, c->sc)); // this step's word only: word 1 of the host copy is k_rmsprop's sticky count
     }
     NVQA_HIP(hipEventRecord(c->evComm, c->sc));
     NVQA_HIP(hipStreamWaitEvent(c->s, c->evComm, 0));

@@ -96,6 +96,10 @@ struct nvqa_ctx {
     nvqa::RideJobs *ride_dev = nullptr;
     bool tok_job_pending = false, ride_gemm_pending = false;
     bool ride_gemm_on = true, tok_in_bptt_on = true; // NVQA_RIDE_GEMM / NVQA_TOK_IN_BPTT (read by nvqa_create)
+    // arch1, f32: the head's image projection rides in the layer-0 workgroups of the persistent FORWARD launch (lstm_persist.h)
+    bool ride_fwd_on = true;                      // NVQA_RIDE_FWD (read by nvqa_create)
+    bool fwd_ride_pending = false, fwd_ride_done = false;
+    nvqa::RideGemm fwd_ride = {};
     int32_t *seg_start = nullptr, *pslot = nullptr;
     uint16_t *perm = nullptr;
     unsigned *seg_done = nullptr;
@@ -186,6 +190,8 @@ struct nvqa_ctx {
     void *comm = nullptr;
     const void *rccl = nullptr; // the collective library's entry points this communicator came from (nvqa_api.hip)
     int rank = 0, world = 1;
+    int dp_slot = 0;            // which of dp_status[0 .. 1] this step uses (they alternate; k_rmsprop clears the next step's)
+    bool dp_clean[2] = {false, false};
     int comm_cus = 0;           // compute units left to the collective while a persistent kernel runs (nvqa_comm_init)
 
     // profiling

@@ -25,7 +25,7 @@ int persist_latch_err(nvqa_ctx *c, unsigned *cnt, size_t words, int off)
     LatchArgs &l = c->latch_pending[off / 4];
     if (l.cnt) NVQA_TRY(latch_flush(c)); // (an older record still waiting for a carrier: latch it now)
     l.cnt = cnt; l.words = (unsigned)words; l.sticky = c->pf_sticky + off;
-    l.dp_status = c->comm ? c->dp_status : nullptr; l.host_copy = c->h_pf_err + off;
+    l.dp_status = c->comm ? c->dp_status + c->dp_slot : nullptr; l.host_copy = c->h_pf_err + off;
     return 0;
 }
 LatchArgs latch_take(nvqa_ctx *c, int which)
@@ -134,6 +134,16 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     a.spin_limit = c->pf_spin ? c->pf_spin : NVQA_PF_SPIN_LIMIT;
     a.cnt = c->pf_cnt; a.err = c->pf_cnt + c->pf_cnt_words - 4; // the last 16 bytes of the block
     a.ts = c->pf_ts;
+    c->fwd_ride_done = false;
+    if (c->fwd_ride_pending && !c->bf16) { // (arch1_forward: the head's image projection, for the layer-0 workgroups' idle tail)
+        a.fr = c->fwd_ride;
+        a.fr_on = 1;
+        c->fwd_ride_done = true;
+        if (c->prof_on) {
+            c->prof[PF_RIDE].flops += 2.0 * c->fwd_ride.g.M * c->fwd_ride.g.N * c->fwd_ride.g.K;
+            c->prof[PF_RIDE].launches += 1;
+        }
+    }
     const int grid = L * a.RB * a.NU;
     double flops = 0;
     for (int l = 0; l < L; ++l) flops += 2.0 * B * 4 * R * ((double)TS * (l == 0 ? d.E : R) + (double)(TS - 1) * R);

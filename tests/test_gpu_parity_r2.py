@@ -332,6 +332,33 @@ def test_ride_along_jobs(pkg, orc):
         assert np.array_equal(got[0][1], got[1][1]), float(np.abs(got[0][1] - got[1][1]).max())
 
 
+def test_image_projection_rides_in_the_forward_launch(pkg, orc):
+    """arch1, f32: layer 0's workgroups of the persistent forward launch finish ~30 % before the launch does (K = E + R against
+    2R per step, and nothing waits for them) and then multiply the head's image projection W_v Dropout(v) -- 128 tiles of
+    64 x 64 x 4096 -- instead of the head's own split-K launch doing it on the critical path (lstm_persist.h:
+    PersistFwdArgs::fr; NVQA_RIDE_FWD=0 switches it off).  The K order of a tile differs from the split-K form, so the two
+    routes agree to f32 summation-order noise, not bit for bit; against the oracle the default route is held by every other
+    arch1 test of this file.  Also at B = 500 (edge tiles) and on a forward-only call."""
+    for kw, full in ((FULL1, True), ({**FULL1, "B": 500}, False)):
+        d = orc.make_dims(**kw)
+        params = orc.synth_params(d)
+        tok, lens, img, lab = orc.synth_batch(d, seed=6, full_length=full, min_len=3)
+        got = []
+        for env in ({}, {"NVQA_RIDE_FWD": "0"}):
+            ctx = _ctx(pkg, d, env)
+            ctx.set_params(params)
+            loss = ctx.step(tok, lens, img, lab, gdrop(pkg, orc.Dropout(1, 0.5, 123, 60)))
+            grads = ctx.get_grads()
+            scores, argmax = ctx.forward(tok, lens, img)
+            l2 = ctx.step(tok, lens, img, lab, gdrop(pkg, orc.Dropout(1, 0.5, 123, 60)))
+            assert l2 == loss and np.array_equal(ctx.get_grads(), grads)   # bit-reproducible on either route
+            got.append((loss, grads, scores))
+            ctx.close()
+        assert abs(got[0][0] - got[1][0]) <= 1e-6 * abs(got[1][0])
+        assert_logits(got[0][2], got[1][2], scale=0.2)
+        assert_grads(orc, d, got[0][1], got[1][1], 2e-6, "fwd_ride_vs_launch")
+
+
 def test_ride_along_jobs_without_a_free_slot(pkg, orc):
     """L = 1, B = 1024: 16 row blocks x 16 unit tiles fill all 256 slots of the BPTT grid -- no workgroup without a role.  The
     jobs must then run in their own launches behind the BPTT (ride_flush / emb_backward's fallback): against the oracle."""
