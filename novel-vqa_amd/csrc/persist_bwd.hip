@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "lstm_persist_bwd2.h"
+#include "lstm_persist_bwd3.h"
 #include "persist_host.h"
 
 namespace nvqa {
@@ -59,6 +60,19 @@ static int launch_persist_bwd2(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
     static int resident = -1;
     NVQA_TRY(check_resident(c, k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>, lds, grid, &resident));
     hipLaunchKernelGGL((k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    NVQA_HIP(hipGetLastError());
+    return 0;
+}
+
+// round 4: the direct-operand form (lstm_persist_bwd3.h); NVQA_BWD_KERNEL=2 keeps round 3's LDS-ring form (A/B runs, fallback tests)
+template <int GKT, int MTA, int MTB, int NTN, int PD, bool BF, bool RAG>
+static int launch_persist_bwd3(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
+{
+    size_t lds = PersistBwd3Geom<MTA, NTN>::LDS_BYTES;
+    if (a.jobs && c->ride.has_tok) lds = std::max(lds, tok_index_lds(c->ride.tok.VT, c->ride.tok.NP));
+    static int resident = -1;
+    NVQA_TRY(check_resident(c, k_lstm_bwd_persist3<GKT, MTA, MTB, NTN, PD, BF, RAG>, lds, grid, &resident));
+    hipLaunchKernelGGL((k_lstm_bwd_persist3<GKT, MTA, MTB, NTN, PD, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -147,12 +161,28 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         if (rag) NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, true>(c, a, grid)));                    \
         else NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, false>(c, a, grid)));                       \
     } while (0)
-        if (c->bf16) {
-            // (4 K groups per chunk -- half the barriers -- measured slower: 0.52 vs 0.45 ms; the step is a chain of latencies)
-            if (L == 1) NVQA_PB2_GO(16, 2, 2, 2, 2, true); else NVQA_PB2_GO(16, 2, 2, 4, 2, true);
+#define NVQA_PB3_GO(GKT, MTA, MTB, NTN, PD, BFv)                                                                    \
+    do {                                                                                                             \
+        if (rag) NVQA_TRY((launch_persist_bwd3<GKT, MTA, MTB, NTN, PD, BFv, true>(c, a, grid)));                     \
+        else NVQA_TRY((launch_persist_bwd3<GKT, MTA, MTB, NTN, PD, BFv, false>(c, a, grid)));                        \
+    } while (0)
+        // f32: the direct-operand kernel (0.89 -> 0.81 ms); bf16: round 3's ring kernel is still the faster one (0.46 against 0.54 ms:
+        // DESIGN.md section 4.6 says where the direct form loses in that mode).  NVQA_BWD_KERNEL=2 / 3 forces one of them.
+        static const int ver_env = [] { const char *e = getenv("NVQA_BWD_KERNEL"); return e ? atoi(e) : 0; }();
+        const int ver = ver_env ? ver_env : (c->bf16 ? 2 : 3);
+        if (ver == 2) {
+            if (c->bf16) {
+                // (4 K groups per chunk -- half the barriers -- measured slower: 0.52 vs 0.45 ms; the step is a chain of latencies)
+                if (L == 1) NVQA_PB2_GO(16, 2, 2, 2, 2, true); else NVQA_PB2_GO(16, 2, 2, 4, 2, true);
+            } else {
+                if (MT == 4) NVQA_PB2_GO(32, 2, 2, 2, 2, false); else NVQA_PB2_GO(32, 4, 3, 2, 2, false);
+            }
+        } else if (c->bf16) {
+            if (L == 1) NVQA_PB3_GO(16, 2, 2, 2, 16, true); else NVQA_PB3_GO(16, 2, 2, 4, 16, true);
         } else {
-            if (MT == 4) NVQA_PB2_GO(32, 2, 2, 2, 2, false); else NVQA_PB2_GO(32, 4, 3, 2, 2, false);
+            if (MT == 4) NVQA_PB3_GO(32, 2, 2, 2, 16, false); else NVQA_PB3_GO(32, 4, 3, 2, 16, false);
         }
+#undef NVQA_PB3_GO
 #undef NVQA_PB2_GO
     }
     NVQA_TRY(persist_latch_err(c, c->pb_cnt, c->pb_cnt_words, 4));
