@@ -143,25 +143,45 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist2(Persis
     constexpr int KG = BF ? 32 : 16;
     const float *W = is_up ? a.Wi[l + 1] : a.Wh[l];
     pf_u32x4 bw[NTN][GKT]; // f32: 4 k = 16 g + 4 lh + w; bf16: 8 k = 32 g + 8 lh + j (packed pairs)
+    if constexpr (!BF) {
 #pragma unroll
-    for (int nt = 0; nt < NTN; ++nt)
+        for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-        for (int g = 0; g < GKT; ++g) {
-            const float *w0 = W + (size_t)(wave * R + KG * g + (KG / 4) * lh) * R + u0 + 16 * nt + li;
-            if constexpr (!BF) {
+            for (int g = 0; g < GKT; ++g) {
+                const float *w0 = W + (size_t)(wave * R + KG * g + (KG / 4) * lh) * R + u0 + 16 * nt + li;
                 bw[nt][g] = __builtin_bit_cast(pf_u32x4, pf_f32x4{w0[0], w0[(size_t)R], w0[2 * (size_t)R], w0[3 * (size_t)R]});
-            } else {
-                pf_u32x4 q;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = pf_pack_bf16(w0[(size_t)(2 * j) * R], w0[(size_t)(2 * j + 1) * R]);
-                // the fragment is born as ONE 128-bit value in an aligned AGPR quad and stays there (the MFMA's B operand, "a"
-                // constraint): assembled from four 32-bit values hipcc kept the pieces apart and copied them into a scratch
-                // AGPR quad in front of every MFMA -- and, not knowing that the asm statement is a matrix instruction, wrote
-                // that quad again while the previous MFMA was still reading it (all-NaN gradients)
-                asm volatile("" : "+a"(q));
-                bw[nt][g] = q;
             }
-        }
+    } else {
+        // bf16: 8 f32 values per fragment, rounded and packed.  Loaded in BATCHES of WB fragments (8 WB loads in flight), packed
+        // afterwards: fragment by fragment -- load 8, pack, pin in an AGPR quad -- the prologue was a chain of GKT x NTN = 64 global
+        // round trips, 60-80 us of a 0.45 ms launch (r4 timestamps: "weights resident after 62.7 .. 80.2 us" against 6 .. 12 us in f32).
+        constexpr int WB = 8;
+        static_assert(GKT % WB == 0, "whole batches");
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int g0 = 0; g0 < GKT; g0 += WB) {
+                float raw[WB][8];
+#pragma unroll
+                for (int gg = 0; gg < WB; ++gg) {
+                    const float *w0 = W + (size_t)(wave * R + KG * (g0 + gg) + (KG / 4) * lh) * R + u0 + 16 * nt + li;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) raw[gg][j] = w0[(size_t)j * R];
+                }
+#pragma unroll
+                for (int gg = 0; gg < WB; ++gg) {
+                    pf_u32x4 q;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = pf_pack_bf16(raw[gg][2 * j], raw[gg][2 * j + 1]);
+                    // the fragment is born as ONE 128-bit value in an aligned AGPR quad and stays there (the MFMA's B operand, "a"
+                    // constraint): assembled from four 32-bit values hipcc kept the pieces apart and copied them into a scratch
+                    // AGPR quad in front of every MFMA -- and, not knowing that the asm statement is a matrix instruction, wrote
+                    // that quad again while the previous MFMA was still reading it (all-NaN gradients)
+                    asm volatile("" : "+a"(q));
+                    bw[nt][g0 + gg] = q;
+                }
+            }
+    }
     if ((a.dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 1] = wall_clock64();
 
     const size_t gt_bytes = (size_t)TS * B * 4 * R * 4, pup_bytes = (size_t)TS * B * R * 4;

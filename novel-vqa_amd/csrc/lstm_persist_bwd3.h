@@ -17,37 +17,52 @@
 // buffer is doubled so that no second one is needed, and the hand-off signal (every storing wave drains with a counted
 // s_waitcnt, then the workgroup's ONE agent-scope add) goes through an LDS arrival counter instead of a barrier
 // (MI355X_MICROARCH.md "Valid forms", Consumer bullet condition (3), second alternative).
+//
+// NH independent row CHAINS per workgroup (lstm_persist_bwd2.h has two "halves"): the row tiles of a block are dealt to the
+// chains round-robin, a step is NH chain-steps, and while one chain's hand-off travels (stores drained, counter, the consumers'
+// poll, their loads: ~5 us) the workgroup multiplies the others.  f32 is MFMA-bound -- a chain-step of 3 or 4 row tiles is
+// 13-17 us of MFMAs -- and two chains hide the hand-off; in bf16 a chain-step is ~2 us, so the 4 row tiles of a block run as
+// FOUR chains of one tile.
 // Measured (B = 512, T = 26, R = 512): DESIGN.md section 4.6.
 #pragma once
 #include "lstm_persist_bwd2.h"
 
 namespace nvqa {
 
-template <int MTA, int NTN> struct PersistBwd3Geom {
+template <int MTA, int NTN, int NH = 2> struct PersistBwd3Geom {
     static constexpr int ROWSH = 16 * MTA, UNITS = 16 * NTN;
     static constexpr int QPR = UNITS / 4, RPP = NVQA_PF_THREADS / QPR, NE = (ROWSH + RPP - 1) / RPP; // epilogue items per thread and half
     static constexpr int SROW = UNITS + 4;                     // row stride of a partial tile (lstm_persist_bwd2.h: conflict-free spill)
     static constexpr int SRED = 4 * ROWSH * SROW;              // floats of one buffer of partial tiles [4 waves][ROWSH][SROW]
     static constexpr int BSUM_FLOATS = NVQA_PF_THREADS * 16;
-    static constexpr int DC_FLOATS = NVQA_PF_THREADS * 2 * NE * 4 * 2;
+    static constexpr int DC_FLOATS = NVQA_PF_THREADS * NH * NE * 4 * 2;
     static constexpr size_t LDS_BYTES = (size_t)(2 * SRED + BSUM_FLOATS + DC_FLOATS + 4) * 4;
 };
 
-// GKT: K groups per gate in all (R / 16 in f32, R / 32 in bf16); MTA / MTB: row tiles of half 0 / 1; NTN column tiles of 16 units;
-// PD: fragment loads in flight per lane (ring of PD x 4 registers)
-template <int GKT, int MTA, int MTB, int NTN, int PD, bool BF, bool RAG>
+// row tiles of chain h when TILES tiles are dealt round-robin to NH chains
+constexpr int pb3_mt(int tiles, int nh, int h) { return (tiles - h + nh - 1) / nh; }
+constexpr int pb3_pairs_before(int gkt, int tiles, int nh, int h) { int n = 0; for (int j = 0; j < h; ++j) n += gkt * pb3_mt(tiles, nh, j); return n; }
+
+// GKT: K groups per gate in all (R / 16 in f32, R / 32 in bf16); TILES: row tiles of 16 rows per row block, dealt round-robin to NH
+// chains (chain h: pb3_mt(TILES, NH, h) of them); NTN column tiles of 16 units; PD: fragment loads in flight per lane (ring of PD x 4 registers)
+template <int GKT, int TILES, int NH, int NTN, int PD, bool BF, bool RAG>
 __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(PersistBwd2Args a)
 {
-    typedef PersistBwd3Geom<MTA, NTN> GE;
-    static_assert(MTA >= MTB && MTB >= 1, "half 0 is the larger half");
+    constexpr int MTA = pb3_mt(TILES, NH, 0);       // the largest chain
+    typedef PersistBwd3Geom<MTA, NTN, NH> GE;
+    static_assert(NH >= 2 && TILES >= NH, "every chain has a row tile; one chain alone cannot hide its own hand-off");
     constexpr int ROWSH = GE::ROWSH, UNITS = GE::UNITS, SROW = GE::SROW, SRED = GE::SRED;
     constexpr int ES = BF ? 2 : 4;                  // bytes per A element
-    constexpr int P0 = GKT * MTA, P1 = GKT * MTB;   // (K group, row tile) pairs of a half-step of half 0 / 1
-    static_assert((P0 + P1) % PD == 0 && PD <= P1, "the fragment ring keeps its phase across a pair of half-steps");
+    // (K group, row tile) pairs of a chain-step of chain h: GKT * pb3_mt(h); the fragment ring keeps its phase across a whole step
+    static_assert(pb3_pairs_before(GKT, TILES, NH, NH) % PD == 0, "the fragment ring keeps its phase across a whole step");
+    // f32: PD fragments in flight, the next chain-step's first PD ride in the current one's tail (PD <= pairs of the smallest chain-step).
+    // bf16: the ring holds TWO whole chain-steps (all chains alike: PD = 2 P) and chain-step k + 2's fragments are requested behind
+    // chain-step k's stream, a whole chain-step ahead of their use.
+    static_assert(BF ? (TILES % NH == 0 && PD == 2 * GKT * (TILES / NH)) : PD <= GKT * pb3_mt(TILES, NH, NH - 1), "ring depth");
     extern __shared__ __attribute__((aligned(16))) float pb3_smem[];
     float *const Sred = pb3_smem;                   // [2][4 waves][ROWSH][SROW] partial tiles of half-step k in buffer k & 1
     float *const bsum = pb3_smem + 2 * SRED;        // [4 gates][thread][4 units] (lstm_persist_bwd2.h)
-    float *const dcs = bsum + GE::BSUM_FLOATS;      // [half][item][2][thread][4 units]: carried cell gradient, carried cell state
+    float *const dcs = bsum + GE::BSUM_FLOATS;      // [chain][item][2][thread][4 units]: carried cell gradient, carried cell state
     unsigned *const sigcnt = reinterpret_cast<unsigned *>(dcs + GE::DC_FLOATS); // arrivals of the waves at a hand-off signal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lh = lane >> 4;
     const int B = a.B, R = a.R, TS = a.TS, L = a.L, RBn = a.RB;
@@ -84,21 +99,45 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     constexpr int KG = BF ? 32 : 16;
     const float *W = is_up ? a.Wi[l + 1] : a.Wh[l];
     pf_u32x4 bw[NTN][GKT]; // f32: 4 k = 16 g + 4 lh + w; bf16: 8 k = 32 g + 8 lh + j (packed pairs)
+    if constexpr (!BF) {
 #pragma unroll
-    for (int nt = 0; nt < NTN; ++nt)
+        for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-        for (int g = 0; g < GKT; ++g) {
-            const float *w0 = W + (size_t)(wave * R + KG * g + (KG / 4) * lh) * R + u0 + 16 * nt + li;
-            if constexpr (!BF) {
+            for (int g = 0; g < GKT; ++g) {
+                const float *w0 = W + (size_t)(wave * R + KG * g + (KG / 4) * lh) * R + u0 + 16 * nt + li;
                 bw[nt][g] = __builtin_bit_cast(pf_u32x4, pf_f32x4{w0[0], w0[(size_t)R], w0[2 * (size_t)R], w0[3 * (size_t)R]});
-            } else {
-                pf_u32x4 q;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = pf_pack_bf16(w0[(size_t)(2 * j) * R], w0[(size_t)(2 * j + 1) * R]);
-                asm volatile("" : "+a"(q)); // born in an aligned AGPR quad (lstm_persist_bwd2.h)
-                bw[nt][g] = q;
             }
-        }
+    } else {
+        // bf16: 8 f32 values per fragment, rounded and packed.  Loaded in BATCHES of WB fragments (8 WB loads in flight), packed
+        // afterwards: fragment by fragment -- load 8, pack, pin in an AGPR quad -- the prologue was a chain of GKT x NTN = 64 global
+        // round trips, 60-80 us of a 0.45 ms launch (r4 timestamps: "weights resident after 62.7 .. 80.2 us" against 6 .. 12 us in f32).
+        constexpr int WB = 8;
+        static_assert(GKT % WB == 0, "whole batches");
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int g0 = 0; g0 < GKT; g0 += WB) {
+                float raw[WB][8];
+#pragma unroll
+                for (int gg = 0; gg < WB; ++gg) {
+                    const float *w0 = W + (size_t)(wave * R + KG * (g0 + gg) + (KG / 4) * lh) * R + u0 + 16 * nt + li;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) raw[gg][j] = w0[(size_t)j * R];
+                }
+#pragma unroll
+                for (int gg = 0; gg < WB; ++gg) {
+                    pf_u32x4 q;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = pf_pack_bf16(raw[gg][2 * j], raw[gg][2 * j + 1]);
+                    // the fragment is born as ONE 128-bit value in an aligned AGPR quad and stays there (the MFMA's B operand, "a"
+                    // constraint): assembled from four 32-bit values hipcc kept the pieces apart and copied them into a scratch
+                    // AGPR quad in front of every MFMA -- and, not knowing that the asm statement is a matrix instruction, wrote
+                    // that quad again while the previous MFMA was still reading it (all-NaN gradients)
+                    asm volatile("" : "+a"(q));
+                    bw[nt][g0 + gg] = q;
+                }
+            }
+    }
     if ((dbg & 32) && tid == 0) a.ts[blockIdx.x * 4 + 1] = wall_clock64();
 
     const size_t gt_bytes = (size_t)TS * B * 4 * R * 4, pup_bytes = (size_t)TS * B * R * 4;
@@ -107,24 +146,24 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     const __amdgpu_buffer_rsrc_t r_g = pf_rsrc(a.Gt[l], gt_bytes);                   // REC: gates in / dG out
     const __amdgpu_buffer_rsrc_t r_p = pf_rsrc(l + 1 < L ? a.Pup[l] : a.Gt[l], l + 1 < L ? pup_bytes : gt_bytes);
 
-    // local row i of the block <-> sorted batch row rb + RBn i; rows 0 .. nloc-1 exist.  Row rho of half h is local row
-    // rho + 16 (rho / 16) + 16 h (tile 2m + h).
+    // local row i of the block <-> sorted batch row rb + RBn i; rows 0 .. nloc-1 exist.  Row rho of chain h is local row
+    // (rho % 16) + 16 (NH (rho / 16) + h): its tile m is tile NH m + h of the block.
     const int nloc = (B - rb + RBn - 1) / RBn;
-    // this lane's fragment of (half h, row tile m, K group g): 16 bytes at
-    //   row (rb + RBn (li + 16 (2m + h))) of slice sa, element wave * R + KG g + (KG / 4) lh
+    // this lane's fragment of (chain h, row tile m, K group g): 16 bytes at
+    //   row (rb + RBn (li + 16 (NH m + h))) of slice sa, element wave * R + KG g + (KG / 4) lh
     // = voff[h][m] + sa * step_bytes + 64 g  (the 64 g goes into the load's immediate offset field)
     const unsigned row_bytes = 4u * R * ES, step_bytes = (unsigned)B * row_bytes;
-    unsigned voff[2][MTA];
+    unsigned voff[NH][MTA];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int m = 0; m < MTA; ++m) {
-            const int iloc = li + 16 * (2 * m + h);
-            const bool ok = m < (h ? MTB : MTA) && iloc < nloc;
+            const int iloc = li + 16 * (NH * m + h);
+            const bool ok = m < pb3_mt(TILES, NH, h) && iloc < nloc;
             voff[h][m] = ok ? (unsigned)(rb + RBn * iloc) * row_bytes + (unsigned)(wave * R + (KG / 4) * lh) * ES : PF_OOB;
         }
-    // half-step k = 2 (TS-1-s) + h
-    auto kstep = [&](int k) __attribute__((always_inline)) { return TS - 1 - (k >> 1); };
+    // chain-step k = NH (TS-1-s) + h
+    auto kstep = [&](int k) __attribute__((always_inline)) { return TS - 1 - k / NH; };
     // A slice of half-step k: REC: dG^l_{s+1}; UP: dG^{l+1}_s
     auto ksa = [&](int k) __attribute__((always_inline)) { return is_up ? kstep(k) : kstep(k) + 1; };
 
@@ -165,14 +204,14 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     constexpr int QPR = GE::QPR, RPP = GE::RPP, NE = GE::NE;
     static_assert(RPP % 16 == 0, "an epilogue pass covers whole row tiles");
     const int eq = tid % QPR, erow = tid / QPR;
-    auto eloc = [&](int h, int e) __attribute__((always_inline)) { const int rho = erow + RPP * e; return rho + 16 * (rho >> 4) + 16 * h; };
-    int esi[2][NE];       // original batch row of the owned rows (indexes the dropout stream)
+    auto eloc = [&](int h, int e) __attribute__((always_inline)) { const int rho = erow + RPP * e; return (rho & 15) + 16 * (NH * (rho >> 4) + h); };
+    int esi[NH][NE];      // original batch row of the owned rows (indexes the dropout stream)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int iloc = eloc(h, e), grow = rb + RBn * iloc;
-            const bool ok = erow + RPP * e < 16 * (h ? MTB : MTA) && iloc < nloc;
+            const bool ok = erow + RPP * e < 16 * pb3_mt(TILES, NH, h) && iloc < nloc;
             pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (!is_up && ok) v = *reinterpret_cast<const pf_f32x4 *>(a.dCT + ((size_t)l * B + grow) * R + u0 + 4 * eq);
             *reinterpret_cast<pf_f32x4 *>(dcs + (((h * NE + e) * 2) * NVQA_PF_THREADS + tid) * 4) = v; // REC: the carried cell gradient of the owned (row, unit)s
@@ -187,21 +226,23 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     for (int g = 0; g < 4; ++g) *reinterpret_cast<pf_f32x4 *>(bsum + (g * NVQA_PF_THREADS + tid) * 4) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 
     // counters (lstm_persist_bwd2.h)
-    const unsigned crec = (unsigned)(((l * RBn + rb) * 2) * TS);
-    const unsigned cneed = (unsigned)(((la * RBn + rb) * 2) * TS);
-    const unsigned cup = (unsigned)((((l * RBn + rb) * 2) * NU) * TS);
-    auto need_word = [&](int k) __attribute__((always_inline)) { return cnt_rec + cneed + (unsigned)((k & 1) * TS + ksa(k)); };
+    // counters: lstm_persist_bwd2.h's layout with NH chains in place of its two halves
+    const unsigned crec = (unsigned)(((l * RBn + rb) * NH) * TS);
+    const unsigned cneed = (unsigned)(((la * RBn + rb) * NH) * TS);
+    const unsigned cup = (unsigned)((((l * RBn + rb) * NH) * NU) * TS);
+    auto need_word = [&](int k) __attribute__((always_inline)) { return cnt_rec + cneed + (unsigned)((k % NH) * TS + ksa(k)); };
     auto own_word = [&](int k) __attribute__((always_inline)) {
-        return is_up ? cnt_up + cup + (unsigned)(((k & 1) * NU + ut) * TS + kstep(k)) : cnt_rec + crec + (unsigned)((k & 1) * TS + kstep(k));
+        return is_up ? cnt_up + cup + (unsigned)(((k % NH) * NU + ut) * TS + kstep(k)) : cnt_rec + crec + (unsigned)((k % NH) * TS + kstep(k));
     };
-    auto up_word = [&](int k) __attribute__((always_inline)) { return cnt_up + cup + (unsigned)(((k & 1) * NU + ut) * TS + kstep(k)); };
-    // RAG: active tiles of half h at step s (rows dealt round-robin: the active local rows are a prefix)
+    auto up_word = [&](int k) __attribute__((always_inline)) { return cnt_up + cup + (unsigned)(((k % NH) * NU + ut) * TS + kstep(k)); };
+    // RAG: active tiles of chain h at step s (rows dealt round-robin: the active local rows are a prefix)
     auto act_of = [&](int h, int s) __attribute__((always_inline)) -> int {
-        if constexpr (!RAG) return h ? MTB : MTA;
+        const int mth = pb3_mt(TILES, NH, h);
+        if constexpr (!RAG) return mth;
         const int nr = nrows_p[s < 0 ? 0 : (s >= TS ? TS - 1 : s)];
         const int tiles = ((nr > rb ? (nr - rb + RBn - 1) / RBn : 0) + 15) >> 4; // local tiles with active rows
-        const int t = (tiles - h + 1) >> 1;
-        return __builtin_amdgcn_readfirstlane(min(h ? MTB : MTA, max(t, 0)));
+        const int t = (tiles - h + NH - 1) / NH;
+        return __builtin_amdgcn_readfirstlane(min(mth, max(t, 0)));
     };
 
     // cell-backward operands of one item (own gates and cell states of the forward pass: default-policy loads, issued on EVERY
@@ -236,7 +277,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
 
     // ---- reduction of the four K-quarters + cell backward (REC) / tile store (UP) of half-step (h, s) --------------------
     auto spill_acc = [&](auto h_tag, int buf) __attribute__((always_inline)) {
-        constexpr int H = decltype(h_tag)::value, MT = H ? MTB : MTA;
+        constexpr int H = decltype(h_tag)::value, MT = pb3_mt(TILES, NH, H);
         float *const S = Sred + buf * SRED;
         pb_nop_before_read();
 #pragma unroll
@@ -249,7 +290,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     // prod = false: no product at this half-step (REC at the last step); head_now: arch1's head term of a layer below the top
     // (only at s = TS-1, which has no product: loaded here, where no prefetch is in flight that it would drain)
     auto cell_item = [&](auto h_tag, auto e_tag, int s, bool prod, int nr, int buf, bool head_now) __attribute__((always_inline)) {
-        constexpr int H = decltype(h_tag)::value, MT = H ? MTB : MTA, e = decltype(e_tag)::value;
+        constexpr int H = decltype(h_tag)::value, MT = pb3_mt(TILES, NH, H), e = decltype(e_tag)::value;
         const float *const S = Sred + buf * SRED;
         const int rho = erow + RPP * e, iloc = eloc(H, e), grow = rb + RBn * iloc;
         if (rho >= 16 * MT || iloc >= nloc || (dbg & 2)) return;
@@ -324,19 +365,20 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
             __hip_atomic_fetch_add(own_word(__builtin_amdgcn_readfirstlane(k)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
-    const int KN = 2 * TS;              // half-steps
-    const int k0 = is_up ? 0 : 2;       // first half-step with a product (REC at the last step has none)
+    const int KN = NH * TS;             // chain-steps
+    const int k0 = is_up ? 0 : NH;      // first chain-step with a product (REC at the last step has none)
     __syncthreads();                    // sigcnt, the carried state
     // ---- REC at the last step: head term (+ the UP tile) and the cell backward only ----------------------------------------
     for (int k = 0; k < k0 && k < KN; ++k) {
-        const int s = kstep(k), h = k & 1;
+        const int s = kstep(k), h = k % NH;
 #pragma unroll
         for (int e = 0; e < NE; ++e) fetch(h, s, e);
         if (has_up && !(dbg & 1)) (void)pf_wait_ge(up_word(k), 1u, errw, 0x500u + l, spin_limit);
         fetch_v2(h, s);
         const int nr0 = nrows_p[s];
-        if (h == 0) cell_all(std::integral_constant<int, 0>{}, s, false, nr0, 0, true);
-        else cell_all(std::integral_constant<int, 1>{}, s, false, nr0, 0, true);
+        [&]<int... Hh>(std::integer_sequence<int, Hh...>) __attribute__((always_inline)) {
+            ((h == Hh ? cell_all(std::integral_constant<int, Hh>{}, s, false, nr0, 0, true) : (void)0), ...);
+        }(std::make_integer_sequence<int, NH>{});
         signal_now(k);
     }
 
@@ -346,7 +388,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     const unsigned dbg_oob = __builtin_amdgcn_readfirstlane((dbg & 8) ? PF_OOB : 0u);
     // base offsets of the lane's rows for a half-step (half H, slice sa, `act` active tiles, enabled or not)
     auto bases = [&](auto h_tag, int sa, int act, bool en, unsigned (&b)[MTA]) __attribute__((always_inline)) {
-        constexpr int H = decltype(h_tag)::value, MT = H ? MTB : MTA;
+        constexpr int H = decltype(h_tag)::value, MT = pb3_mt(TILES, NH, H);
         const unsigned enm = __builtin_amdgcn_readfirstlane(en ? 0u : PF_OOB) | dbg_oob;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -361,57 +403,98 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
     };
     unsigned bcur[MTA], bnxt[MTA];
     if (k0 < KN) {
-        // pipeline prologue for half-step k0 (half 0): its producers' counter, the first PD fragments
+        // pipeline prologue for chain-step k0 (chain 0): its producers' counter, the first fragments
         if (!(dbg & 1)) (void)pf_wait_ge(need_word(k0), (unsigned)NU, errw, (is_up ? 0x400u : 0x300u) + l, spin_limit);
         bases(std::integral_constant<int, 0>{}, ksa(k0), act_of(0, kstep(k0)), true, bcur);
-        [&]<int... Pp>(std::integer_sequence<int, Pp...>) __attribute__((always_inline)) {
-            ((af[Pp % PD] = ldA(bcur[Pp % MTA], std::integral_constant<int, Pp / MTA>{})), ...);
-        }(std::make_integer_sequence<int, PD>{});
+        if constexpr (!BF) {
+            [&]<int... Pp>(std::integer_sequence<int, Pp...>) __attribute__((always_inline)) {
+                ((af[Pp % PD] = ldA(bcur[Pp % MTA], std::integral_constant<int, Pp / MTA>{})), ...);
+            }(std::make_integer_sequence<int, PD>{});
+        } else { // bf16: all of chain-step k0 and all of chain-step k0 + 1 (chain 1)
+            constexpr int PC = PD / 2;
+            [&]<int... Pp>(std::integer_sequence<int, Pp...>) __attribute__((always_inline)) {
+                ((af[Pp] = ldA(bcur[Pp % MTA], std::integral_constant<int, Pp / MTA>{})), ...);
+            }(std::make_integer_sequence<int, PC>{});
+            const bool more1 = k0 + 1 < KN;
+            if (more1 && !(dbg & 1)) (void)pf_wait_ge(need_word(k0 + 1), (unsigned)NU, errw, (is_up ? 0x400u : 0x300u) + l, spin_limit);
+            bases(std::integral_constant<int, 1>{}, ksa(more1 ? k0 + 1 : k0), act_of(1, kstep(more1 ? k0 + 1 : k0)), more1, bnxt);
+            [&]<int... Pp>(std::integer_sequence<int, Pp...>) __attribute__((always_inline)) {
+                ((af[PC + Pp] = ldA(bnxt[Pp % MTA], std::integral_constant<int, Pp / MTA>{})), ...);
+            }(std::make_integer_sequence<int, PC>{});
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) fetch(0, kstep(k0), e); // the cell operands of chain-step k0 (every later one: requested at the end of the chain-step before)
     }
 
     // one half-step: H = its half (compile time), k its index.  On entry the fragments of its first PD pairs are in flight and
     // bcur holds its row bases; on exit the same holds for half-step k + 1.
     auto half_step = [&](auto h_tag, int k) __attribute__((always_inline)) {
-        constexpr int H = decltype(h_tag)::value, HN = 1 - H;
-        constexpr int MT = H ? MTB : MTA, MTN = HN ? MTB : MTA, P = GKT * MT;
-        constexpr int RB0 = H ? P0 % PD : 0;   // ring slot of this half-step's pair 0
+        constexpr int H = decltype(h_tag)::value, HN = (H + 1) % NH;
+        constexpr int MT = pb3_mt(TILES, NH, H), MTN = pb3_mt(TILES, NH, HN), P = GKT * MT;
+        constexpr int RB0 = pb3_pairs_before(GKT, TILES, NH, H) % PD;   // ring slot of this chain-step's pair 0
         // where the housekeeping sits in the stream of P pairs (one fragment load per pair, all unconditional):
-        constexpr int PSIG = BF ? 8 : 40;      // drain + signal of the PREVIOUS half-step's stores
-        constexpr int PREQ = P - PD - 6;       // the counters of the next half-step's producers / of this half-step's UP tile are requested
-        constexpr int PV2 = P - 8;             // UP tile (or head term) requested
-        static_assert(PSIG < PREQ && PREQ < P - PD && P - PD <= PV2 && 5 * NE + PSIG <= 63, "order of the housekeeping points; vmcnt is a 6-bit field");
+        // Where the housekeeping sits in the stream of P pairs.
+        // f32 -- the step is MFMA-bound: the next half-step's first PD fragments are requested in this one's last PD pairs (its
+        // producers' counter is looked at just before), so the stream never runs dry.
+        // bf16 -- the step is a chain of latencies (a half-step's MFMAs take 2 us; a hand-off -- stores drained, counter, poll, loads
+        // -- takes 5): a wait in the MIDDLE of the stream for the other chain's producers, whose signals are only 0.3 us old by then,
+        // stalls MFMAs that have their data.  So the next half-step's first PD fragments are requested BEHIND this half-step's
+        // stream (by then the producers signalled a whole half-step ago) and travel under the spill, the cell backward and the
+        // drain of its stores; and the UP tile is requested early instead of 8 pairs (0.2 us) before its use.
+        constexpr bool TAILPF = !BF;           // the next chain-step's first fragments ride in this one's last PD pairs
+        // drain + signal of the PREVIOUS chain-step's stores: f32: 40 pairs in (a counted wait: nothing stalls); bf16: behind this
+        // chain-step's stream (= P), i.e. a chain-step late -- its MFMAs ran under the stores' trip to memory, and with four chains
+        // the consumers still have two chain-steps of slack
+        constexpr int PSIG = TAILPF ? 40 : P;
+        constexpr int PUPQ = BF ? 0 : P - PD - 6; // the flag of this chain-step's UP tile is requested
+        constexpr int PV2 = BF ? 3 : P - 8;    // UP tile (or head term) requested
+        constexpr int PREQ = (TAILPF ? P - PD : P) - 6; // the counter of the next chain-step's producers is requested (looked at 6 pairs on)
+        // memory operations that are YOUNGER than the previous chain-step's stores at the signal point -- all unconditional: the
+        // 5 NE cell operands requested right behind that cell backward, the fragments requested by the pairs in front of it, and
+        // whichever of the UP flag, the UP tile and the producers' counter are requested in front of it
+        constexpr int NFRAG = TAILPF ? PSIG : 0; // (bf16: the stream requests nothing; chain-step k + 1's fragments are older than the stores)
+        constexpr int NYOUNG = 5 * NE + NFRAG + (PUPQ < PSIG ? 1 : 0) + (PV2 < PSIG ? NE : 0) + (PREQ < PSIG ? 1 : 0);
+        static_assert(NYOUNG <= 63, "vmcnt is a 6-bit field");
+        static_assert(PSIG <= P && (!TAILPF || PSIG < P), "the signal point lies in this chain-step");
+        static_assert(PUPQ < PV2 && PV2 < P && PREQ >= 0 && PREQ < P, "a counter is requested before it is looked at");
         const auto HT = std::integral_constant<int, H>{};
         const auto HNT = std::integral_constant<int, HN>{};
         const int s = kstep(k);
         const bool more = k + 1 < KN;
         const int kn = more ? k + 1 : k, sn = kstep(kn), san = ksa(kn);
-        const int act = act_of(H, s), actn = act_of(HN, sn);
+        // the chain-step whose fragments THIS one requests: the next (f32: in its tail) or the one after (bf16: behind its stream)
+        constexpr int LOOK = TAILPF ? 1 : 2, HL = (H + LOOK) % NH, MTL = pb3_mt(TILES, NH, HL);
+        const bool morel = k + LOOK < KN;
+        const int kl = morel ? k + LOOK : k, sal = ksa(kl);
+        const int act = act_of(H, s), actn = act_of(HL, kstep(kl));
         const int nr = nrows_p[s];
 #pragma unroll
         for (int m = 0; m < MTA; ++m)
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) acc[m][nt] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         pb_nop_after_clear();
-        // this half-step's cell operands: consumed behind its product (the previous cell backward has just used the registers)
-#pragma unroll
-        for (int e = 0; e < NE; ++e) fetch(H, s, e);
-        bases(HNT, san, actn, more, bnxt);
+        bases(std::integral_constant<int, HL>{}, sal, actn, morel, bnxt);
         __builtin_amdgcn_sched_barrier(0);
 
         auto pair = [&](auto p_tag) __attribute__((always_inline)) {
             constexpr int p = decltype(p_tag)::value, g = p / MT, m = p % MT, slot = (RB0 + p) % PD;
             if constexpr (p == PSIG) {
-                // memory operations issued since the last store of the previous half-step's cell backward: this half-step's
-                // 5 NE cell operands and PSIG fragment loads -- all unconditional -- so at most that many may stay in flight
-                if (pub >= 0) { pb_wait_vmcnt<5 * NE + PSIG>(); signal_wave(pub); pub = -1; }
+                if (pub >= 0) { pb_wait_vmcnt<NYOUNG>(); signal_wave(pub); pub = -1; }
+            }
+            if constexpr (p == PUPQ) {
+                pend_up = __hip_atomic_load(has_up ? up_word(k) : cnt_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::: "memory"); // (pinned here, like the request below)
             }
             if constexpr (p == PREQ) {
-                pend = __hip_atomic_load(more ? need_word(kn) : cnt_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pend_up = __hip_atomic_load(has_up ? up_word(k) : cnt_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend = __hip_atomic_load(morel ? need_word(kl) : cnt_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (pinned HERE: left alone hipcc sinks the two loads to their first use, 6 pairs on, and waits for them with
+                // vmcnt(0) there -- loads return in order, so that drains the whole fragment ring once per half-step; requested
+                // here they are older than the 6 fragments issued meanwhile and the wait leaves those in flight)
+                asm volatile("" ::: "memory");
             }
-            if constexpr (p == P - PD) { // the next half-step's first fragments are requested below: its producers must be done
-                if (more && !(dbg & 1) && pend < (unsigned)NU)
-                    (void)pf_wait_ge(need_word(kn), (unsigned)NU, errw, (is_up ? 0x400u : 0x300u) + l, spin_limit);
+            if constexpr (TAILPF && p == P - PD) { // the next chain-step's first fragments are requested below: its producers must be done
+                if (morel && !(dbg & 1) && pend < (unsigned)NU)
+                    (void)pf_wait_ge(need_word(kl), (unsigned)NU, errw, (is_up ? 0x400u : 0x300u) + l, spin_limit);
             }
             if constexpr (p == PV2) { // the UP tile of this half-step (normally long since there: UP runs ahead)
                 if (has_up && !(dbg & 1) && pend_up < 1u) (void)pf_wait_ge(up_word(k), 1u, errw, 0x500u + l, spin_limit);
@@ -419,23 +502,40 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
             }
             if (!RAG || m < act) mfma_pair(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot]);
             // the fragment PD pairs ahead takes the slot just consumed
-            if constexpr (p + PD < P) af[slot] = ldA(bcur[(p + PD) % MT], std::integral_constant<int, (p + PD) / MT>{});
-            else af[slot] = ldA(bnxt[(p + PD - P) % MTN], std::integral_constant<int, (p + PD - P) / MTN>{});
+            if constexpr (TAILPF) {
+                if constexpr (p + PD < P) af[slot] = ldA(bcur[(p + PD) % MT], std::integral_constant<int, (p + PD) / MT>{});
+                else af[slot] = ldA(bnxt[(p + PD - P) % MTN], std::integral_constant<int, (p + PD - P) / MTN>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         [&]<int... Pp>(std::integer_sequence<int, Pp...>) __attribute__((always_inline)) { (pair(std::integral_constant<int, Pp>{}), ...); }(std::make_integer_sequence<int, P>{});
+        if constexpr (PSIG == P) {
+            if (pub >= 0) { pb_wait_vmcnt<NYOUNG>(); signal_wave(pub); pub = -1; }
+        }
+        if constexpr (!TAILPF) { // chain-step k + 2's fragments, into the ring half this chain-step has just consumed
+            if (morel && !(dbg & 1) && pend < (unsigned)NU)
+                (void)pf_wait_ge(need_word(kl), (unsigned)NU, errw, (is_up ? 0x400u : 0x300u) + l, spin_limit);
+            [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+                ((af[(RB0 + Q) % PD] = ldA(bnxt[Q % MTL], std::integral_constant<int, Q / MTL>{})), ...);
+            }(std::make_integer_sequence<int, P>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         spill_acc(HT, k & 1);
         __syncthreads();
         cell_all(HT, s, true, nr, k & 1, false);
-        pub = k;
+        // the NEXT half-step's cell operands (the registers are free again; younger than this half-step's stores)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) fetch(HN, sn, e);
+        pub = k; // drained and signalled PSIG pairs into the next half-step (its first MFMAs run under the stores' trip to memory)
 #pragma unroll
         for (int m = 0; m < MTA; ++m) bcur[m] = bnxt[m];
     };
 
-    for (int k = k0; k < KN; k += 2) {
-        half_step(std::integral_constant<int, 0>{}, k);
-        half_step(std::integral_constant<int, 1>{}, k + 1);
+    for (int k = k0; k < KN; k += NH) {
+        [&]<int... Hh>(std::integer_sequence<int, Hh...>) __attribute__((always_inline)) {
+            (half_step(std::integral_constant<int, Hh>{}, k + Hh), ...);
+        }(std::make_integer_sequence<int, NH>{});
     }
     if (pub >= 0) signal_now(pub);
 

@@ -17,9 +17,9 @@ static int persist_bwd_ntn(const nvqa_ctx *c) { return c->bf16 && c->d.L > 1 ? 4
 
 size_t persist_bwd_counter_words(const nvqa_dims &d, int TS)
 {
-    // finest row blocking: 64 rows; two halves; REC counters + UP flags per unit tile of 32 units; + the err record
+    // finest row blocking: 64 rows; up to four chains (lstm_persist_bwd3.h); REC counters + UP flags per unit tile of 32 units; + the err record
     const size_t rbmax = ((size_t)d.B + 63) / 64;
-    return ((size_t)d.L * rbmax * 2 * TS * (1 + (size_t)d.R / 32) + 4 + 3) / 4 * 4;
+    return ((size_t)d.L * rbmax * 4 * TS * (1 + (size_t)d.R / 32) + 4 + 3) / 4 * 4;
 }
 
 int persist_bwd_rows(const nvqa_ctx *c, int *RB)
@@ -65,14 +65,19 @@ static int launch_persist_bwd2(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
 }
 
 // round 4: the direct-operand form (lstm_persist_bwd3.h); NVQA_BWD_KERNEL=2 keeps round 3's LDS-ring form (A/B runs, fallback tests)
-template <int GKT, int MTA, int MTB, int NTN, int PD, bool BF, bool RAG>
-static int launch_persist_bwd3(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
+template <int GKT, int TILES, int NH, int NTN, int PD, bool BF, bool RAG>
+static int launch_persist_bwd3(nvqa_ctx *c, PersistBwd2Args a, int grid)
 {
-    size_t lds = PersistBwd3Geom<MTA, NTN>::LDS_BYTES;
+    {   // the counter block laid out for NH chains (lstm_persist_bwd3.h)
+        const size_t n_rec = (size_t)a.L * a.RB * NH * a.TS, n_up = (size_t)a.L * a.RB * NH * a.NU * a.TS;
+        if (n_rec + n_up + 4 > c->pb_cnt_words) { set_error("persistent BPTT: counter block too small"); return -1; }
+        a.cnt_rec = c->pb_cnt; a.cnt_up = c->pb_cnt + n_rec;
+    }
+    size_t lds = PersistBwd3Geom<pb3_mt(TILES, NH, 0), NTN, NH>::LDS_BYTES;
     if (a.jobs && c->ride.has_tok) lds = std::max(lds, tok_index_lds(c->ride.tok.VT, c->ride.tok.NP));
     static int resident = -1;
-    NVQA_TRY(check_resident(c, k_lstm_bwd_persist3<GKT, MTA, MTB, NTN, PD, BF, RAG>, lds, grid, &resident));
-    hipLaunchKernelGGL((k_lstm_bwd_persist3<GKT, MTA, MTB, NTN, PD, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
+    NVQA_TRY(check_resident(c, k_lstm_bwd_persist3<GKT, TILES, NH, NTN, PD, BF, RAG>, lds, grid, &resident));
+    hipLaunchKernelGGL((k_lstm_bwd_persist3<GKT, TILES, NH, NTN, PD, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
     NVQA_HIP(hipGetLastError());
     return 0;
 }
@@ -161,10 +166,10 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         if (rag) NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, true>(c, a, grid)));                    \
         else NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, false>(c, a, grid)));                       \
     } while (0)
-#define NVQA_PB3_GO(GKT, MTA, MTB, NTN, PD, BFv)                                                                    \
+#define NVQA_PB3_GO(GKT, TILES, NH, NTN, PD, BFv)                                                                   \
     do {                                                                                                             \
-        if (rag) NVQA_TRY((launch_persist_bwd3<GKT, MTA, MTB, NTN, PD, BFv, true>(c, a, grid)));                     \
-        else NVQA_TRY((launch_persist_bwd3<GKT, MTA, MTB, NTN, PD, BFv, false>(c, a, grid)));                        \
+        if (rag) NVQA_TRY((launch_persist_bwd3<GKT, TILES, NH, NTN, PD, BFv, true>(c, a, grid)));                    \
+        else NVQA_TRY((launch_persist_bwd3<GKT, TILES, NH, NTN, PD, BFv, false>(c, a, grid)));                       \
     } while (0)
         // f32: the direct-operand kernel (0.89 -> 0.81 ms); bf16: round 3's ring kernel is still the faster one (0.46 against 0.54 ms:
         // DESIGN.md section 4.6 says where the direct form loses in that mode).  NVQA_BWD_KERNEL=2 / 3 forces one of them.
@@ -177,10 +182,10 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
             } else {
                 if (MT == 4) NVQA_PB2_GO(32, 2, 2, 2, 2, false); else NVQA_PB2_GO(32, 4, 3, 2, 2, false);
             }
-        } else if (c->bf16) {
-            if (L == 1) NVQA_PB3_GO(16, 2, 2, 2, 16, true); else NVQA_PB3_GO(16, 2, 2, 4, 16, true);
-        } else {
-            if (MT == 4) NVQA_PB3_GO(32, 2, 2, 2, 16, false); else NVQA_PB3_GO(32, 4, 3, 2, 16, false);
+        } else if (c->bf16) { // four chains of one row tile (a chain-step is ~2 us: two chains do not hide a 5 us hand-off)
+            if (L == 1) NVQA_PB3_GO(16, 4, 4, 2, 32, true); else NVQA_PB3_GO(16, 4, 4, 4, 32, true);
+        } else {              // two chains of 2 + 2 or 4 + 3 row tiles
+            if (MT == 4) NVQA_PB3_GO(32, 4, 2, 2, 16, false); else NVQA_PB3_GO(32, 7, 2, 2, 16, false);
         }
 #undef NVQA_PB3_GO
 #undef NVQA_PB2_GO
