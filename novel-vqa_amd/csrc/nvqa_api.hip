@@ -681,6 +681,7 @@ static int wgrad_bf16(nvqa_ctx *c, const float *A, const unsigned short *A16, in
     const int tiles = ((M + NVQA_WB_BM - 1) / NVQA_WB_BM) * ((N + NVQA_WB_BN - 1) / NVQA_WB_BN);
     int ks = 1;
     while (ks < 16 && tiles * ks < 512 && K / (ks * 2) >= 256) ks *= 2; // measured (round 2): 2048 x 512: 8 slices, 2048 x 200: 16
+    { static const int ks_env = [] { const char *e = getenv("NVQA_WB_KS"); return e ? atoi(e) : 0; }(); if (ks_env > 0) ks = ks_env; } // (sweeps)
     if ((size_t)ks * M * N > c->slab_floats) ks = std::max<int>(1, (int)(c->slab_floats / ((size_t)M * N)));
     int kslice = ((K + ks - 1) / ks + NVQA_WB_BK - 1) / NVQA_WB_BK * NVQA_WB_BK;
     ks = (K + kslice - 1) / kslice;
