@@ -112,8 +112,14 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     double ride_flops = 0;
     if (take_jobs && c->ride_gemm_pending)
         for (int i = 0; i < c->ride.ngemm; ++i) ride_flops += 2.0 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
-    const double bptt_ms = 1e-3 * TS * (c->bf16 ? 17.0 : 34.0) * (L == 1 ? 0.62 : 1.0);
-    const bool keep_gemms = ride_flops * 1e-9 > 3.4 * (bptt_ms / 0.90) * (n_idle / 16.0);
+    // (the calibration is for 7 row tiles per workgroup in f32 (B = 512: 0.9 ms then, 0.81 ms with the round-4 kernel)
+    // and 4 in bf16; a launch with fewer row tiles per workgroup is shorter in proportion, and so is what may ride in it)
+    const int tiles_wg = ((B + 15) / 16 + RB - 1) / RB;
+    const double bptt_ms = 1e-3 * TS * (c->bf16 ? 16.0 : 31.0) * (L == 1 ? 0.62 : 1.0) * std::min(1.0, tiles_wg / (c->bf16 ? 4.0 : 7.0));
+    static const double ride_cap = [] { const char *e = getenv("NVQA_RIDE_CAP"); return e ? atof(e) : 3.8; }(); // GFLOP per 0.90 ms and 16 riders
+    // (round 4: 3.4 -> 3.8 with the direct-operand kernel: the 3.2 GFLOP of dW_o + dW_q still end before its roles do -- measured: step 2.926 ms with
+    // them riding, 2.969 with them behind the launch -- and the launch estimate below shrank with the kernel)
+    const bool keep_gemms = ride_flops * 1e-9 > ride_cap * (bptt_ms / 0.90) * (n_idle / 16.0);
     if (keep_gemms) ride_flops = 0;
     // (the riding products are booked under an entry of their own -- they run on CUs the BPTT roles do not use,
     // and counting their FLOPs in the BPTT phase would flatter its fraction of the peak)
