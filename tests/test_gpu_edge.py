@@ -110,3 +110,30 @@ def test_length_sort_of_a_batch_larger_than_its_workgroup(pkg, orc):
     assert abs(loss - ref["loss"]) <= 2e-6 * abs(ref["loss"])
     assert_grads(orc, d, ctx.get_grads(), ref["grads"], 2e-5, "sort_three_passes")
     ctx.close()
+
+
+@pytest.mark.parametrize("B", [40, 800])
+def test_dataset_route_sample_ids_as_arguments_and_in_device_memory(pkg, orc, B):
+    """nvqa_step_indices hands the sample ids to k_gather_batch as kernel arguments (B <= 768: no H2D blit in front of the
+    step) or, for larger batches, through device memory: both must gather what the host-batch entry is given by hand
+    (dataset:next_batch, 002_train_baseline.lua:202-219), repeated ids included."""
+    d = orc.make_dims(arch=1, B=B, T=7, V=50, E=16, R=16, L=1, I=32, C=24, A=12)
+    params = orc.synth_params(d)
+    rng = np.random.default_rng(5)
+    nq, nimg = 3 * B + 7, 61
+    big = orc.make_dims(**{**{n: getattr(d, n) for n, _ in d._fields_}, "B": nq})
+    tok, lens, _, lab = orc.synth_batch(big, seed=4, full_length=False, min_len=1)
+    feats = np.abs(rng.standard_normal((nimg, d.I))).astype(np.float32)
+    img_pos = rng.integers(1, nimg + 1, nq).astype(np.int32)
+    tr = pkg.trainer.VQATrainer(gdims(pkg, d), 0, seed=123, dropout=True)
+    tr.set_params(params)
+    tr.load_dataset(tok, lens, img_pos, lab, feats, img_norm=True)
+    qinds = rng.integers(0, nq, B).astype(np.int64)     # with replacement, like torch.random
+    dr = tr._dropout()
+    la = tr.ctx.step_indices(qinds, dr)
+    ga = tr.ctx.get_grads()
+    fn = feats / np.sqrt((feats * feats).sum(1, keepdims=True))
+    lb = tr.ctx.step(tok[qinds], lens[qinds], fn[img_pos[qinds] - 1], lab[qinds], dr)
+    gb = tr.ctx.get_grads()
+    assert abs(la - lb) <= 1e-6 * abs(lb) and relmax(ga, gb) < 1e-5
+    tr.close()
