@@ -1204,16 +1204,16 @@ static int arch1_forward(nvqa_ctx *c, const Drop &dr, bool train, bool want_argm
 }
 
 // Head weight gradients that only the optimiser needs: in single-GPU runs they ride in the idle workgroups of the persistent
-// BPTT launch (ride_jobs.h) instead of taking their time on the critical path in front of it.  (With a communicator the
-// segment they belong to is exchanged before the BPTT, and the idle slots belong to the collective's kernels: computed in
-// place then.)  NVQA_RIDE_GEMM=0: always in place.
+// BPTT launch (ride_jobs.h) instead of taking their time on the critical path in front of it -- with a communicator too, since
+// round 4 exchanges their segment BEHIND the BPTT launch (nvqa_comm_init).  Only NVQA_DP_OVERLAP_BPTT=1 (the segment travels under
+// the BPTT, and the idle slots belong to the collective's kernels) computes them in place, as NVQA_RIDE_GEMM=0 always does.
 static bool ride_begin(nvqa_ctx *c)
 {
     int rb = 0;
     c->ride.ngemm = 0;
     c->ride.has_colsum = 0;
     c->ride_gemm_pending = false;
-    return c->ride_gemm_on && !c->comm && persist_bwd_rows(c, &rb) != 0;
+    return c->ride_gemm_on && (!c->comm || !c->dp_overlap_bptt) && persist_bwd_rows(c, &rb) != 0;
 }
 static void ride_add(nvqa_ctx *c, const GemmArgs &g, const EpiStore &e)
 {
@@ -1253,8 +1253,7 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
         // classifier: dW_o = dscores^T zd ; d(zd) = dscores W_o -> Dropout', CMul', Tanh'
         const int ZW = c->fusion_askip == 2 ? 2 * C : C;
         // dW_o and dW_q are needed only by the optimiser: in single-GPU runs they ride in the idle workgroups of the persistent
-        // BPTT launch (ride_jobs.h) instead of taking 40 us of the critical path here.  (With a communicator the multimodal
-        // segment is exchanged before the BPTT, so they are computed here.)  NVQA_RIDE_GEMM=0: always here.
+        // BPTT launch (ride_jobs.h) instead of taking 40 us of the critical path here (ride_begin says when).
         if (ride) ride_add(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0});
         else NVQA_TRY((gemm_med<A_MC, B_NC>(c, mkargs(c->dscores, A, c->zd, ZW, A, ZW, B), EpiStore{G + c->lo.w_o, ZW, 0})));
         NVQA_TRY((gemm_med<A_KC, B_NC>(c, mkargs(c->dscores, A, c->P + c->lo.w_o, ZW, B, ZW, A),
@@ -1288,10 +1287,11 @@ static int arch1_backward(nvqa_ctx *c, const Drop &dr)
             NVQA_HIP(hipGetLastError());
         }
     }
-    NVQA_TRY(reduce_segment(c, 2)); // multimodal gradients are final: their all-reduce hides under BPTT
+    if (c->dp_overlap_bptt) NVQA_TRY(reduce_segment(c, 2)); // NVQA_DP_OVERLAP_BPTT=1: the multimodal segment's all-reduce hides under the BPTT
     float *dX0 = c->dX0;
     NVQA_TRY(lstm_backward(c, dr));
     NVQA_TRY(ride_flush(c));
+    if (!c->dp_overlap_bptt) NVQA_TRY(reduce_segment(c, 2)); // default: behind the BPTT launch (no collective beside a persistent kernel), under what follows
     // embedding gradient first, so that its 11.8 MB all-reduce and those of the upper LSTM layers travel
     // under the weight-gradient GEMMs; only layer 0's slice (5.8 MB) is exchanged after the last kernel
     NVQA_TRY(lstm_dx0(c, dX0));
@@ -1394,9 +1394,10 @@ static int arch2_backward(nvqa_ctx *c, const Drop &dr)
             NVQA_HIP(hipGetLastError());
         }
     }
-    NVQA_TRY(reduce_segment(c, 2)); // classifier
+    if (c->dp_overlap_bptt) NVQA_TRY(reduce_segment(c, 2)); // classifier
     NVQA_TRY(lstm_backward(c, dr));
     NVQA_TRY(ride_flush(c));
+    if (!c->dp_overlap_bptt) NVQA_TRY(reduce_segment(c, 2));
     NVQA_TRY(lstm_dx0(c, c->dX0));
     {   // cnn_projection:backward (002_train_baseline.lua:322): dW_p = dx_1^T fv_im, db_p = colsum(dx_1)
         ProfScope ps(c, PF_GEMM_HEAD_BWD, 2.0 * B * E * I, ((double)B * (E + I) + (double)E * I) * 4);
@@ -1907,14 +1908,21 @@ extern "C" int nvqa_comm_init(nvqa_ctx *c, int rank, int world, const void *id)
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world %d/%d", rank, world); return -1; }
     if (c->comm) { set_error("nvqa_comm_init: the context already has a communicator"); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
-    {   // Co-residency policy.  The persistent BPTT kernel needs all its workgroups resident at once
-        // (240 of the 256 CUs in f32, 192 in bf16) while the multimodal all-reduce travels underneath it on the communication
-        // stream; a collective kernel holds one CU per channel while it runs.  The library therefore leaves the collective
-        // NVQA_COMM_CUS compute units (default 16) and, unless the caller has set it, caps RCCL's channels at that number
-        // BEFORE the communicator is created; persist_bwd_rows() refuses the persistent path when its grid would not leave
-        // them free.  (The forward kernel takes every CU: no exchange is in flight then -- reduce_join ends the step.)
+    {   // When is the multimodal segment exchanged?
+        // Default (round 4): BEHIND the persistent BPTT launch, with everything else.  No collective kernel ever runs beside a persistent
+        // launch then -- the forward launch never had one beside it (reduce_join ends the step) -- so there is no co-residency to
+        // arrange: RCCL keeps its own channel count (the cap below costs it bandwidth), the BPTT grid needs no reserve, and the head's
+        // weight gradients ride in its idle workgroups as in single-GPU runs.  The 55 MB then travel under the 1.0 ms of d(input),
+        // embedding gradient and weight-gradient GEMMs that follow the BPTT -- ordinary kernels that share CUs with a collective.
+        // NVQA_DP_OVERLAP_BPTT=1 (round 3's order): the segment travels UNDER the BPTT launch, which needs all its workgroups
+        // resident at once (240 of the 256 CUs in f32) while a collective kernel holds one CU per channel: the library leaves the
+        // collective NVQA_COMM_CUS compute units (default 16), caps RCCL's channels at that number BEFORE the communicator is created
+        // unless the caller has set them, and persist_bwd_rows() refuses the persistent path when its grid would not leave them free.
+        const char *eo = getenv("NVQA_DP_OVERLAP_BPTT");
+        c->dp_overlap_bptt = eo && eo[0] == '1';
+        c->comm_cus = 0;
         const char *e = getenv("NVQA_COMM_CUS");
-        c->comm_cus = e ? atoi(e) : 16;
+        if (c->dp_overlap_bptt) c->comm_cus = e ? atoi(e) : 16;
         if (c->comm_cus > 0) {
             char buf[16];
             snprintf(buf, sizeof(buf), "%d", c->comm_cus);

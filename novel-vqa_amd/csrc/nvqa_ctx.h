@@ -192,6 +192,7 @@ struct nvqa_ctx {
     int rank = 0, world = 1;
     int dp_slot = 0;            // which of dp_status[0 .. 1] this step uses (they alternate; k_rmsprop clears the next step's)
     bool dp_clean[2] = {false, false};
+    bool dp_overlap_bptt = false; // NVQA_DP_OVERLAP_BPTT=1: the multimodal segment is exchanged UNDER the persistent BPTT launch (round 3's order)
     int comm_cus = 0;           // compute units left to the collective while a persistent kernel runs (nvqa_comm_init)
 
     // profiling

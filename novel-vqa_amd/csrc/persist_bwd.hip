@@ -32,7 +32,7 @@ int persist_bwd_rows(const nvqa_ctx *c, int *RB)
     *RB = (mtiles + MT - 1) / MT;
     if ((2 * d.L - 1) * *RB * NU > c->num_cus || c->num_cus < 256 || (2 * d.L - 1) * *RB > 8 * (32 / NU)) return 0;
     // data parallel: an all-reduce is in flight during BPTT; its kernel keeps the CUs nvqa_comm_init left it
-    if (c->comm && (2 * d.L - 1) * *RB * NU + c->comm_cus > c->num_cus) return 0;
+    if (c->comm && c->dp_overlap_bptt && (2 * d.L - 1) * *RB * NU + c->comm_cus > c->num_cus) return 0;
     return MT;
 }
 

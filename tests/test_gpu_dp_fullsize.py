@@ -54,9 +54,15 @@ def _run(pkg, orc, d, params, batch, world, bf16, steps=3):
     return out, min(times[1:])
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_persistent_kernels_beside_a_cu_holding_collective(pkg, orc, monkeypatch, name):
+def test_persistent_kernels_beside_a_cu_holding_collective(pkg, orc, monkeypatch, name, overlap):
+    """overlap = "1": round 3's order (NVQA_DP_OVERLAP_BPTT=1), the multimodal segment's all-reduce runs UNDER the persistent BPTT
+    launch -- the case the docstring above describes.  overlap = "0": round 4's default, every segment is exchanged behind the
+    BPTT launch (no collective beside a persistent kernel; the head's weight gradients ride in the launch as in single-GPU runs)
+    and the CU-holding collective shares the chip with the ordinary kernels that follow."""
     assert os.path.exists(SHIM), "tests/shim/libnccl_shim.so missing: run __graft_entry__.build()"
+    monkeypatch.setenv("NVQA_DP_OVERLAP_BPTT", overlap)
     kw, bf16 = CASES[name]
     d = orc.make_dims(**kw)
     params = orc.synth_params(d)
@@ -73,7 +79,7 @@ def test_persistent_kernels_beside_a_cu_holding_collective(pkg, orc, monkeypatch
             assert a[0] == b[0], (cus, it, "loss")
             assert np.array_equal(a[1], b[1]), (cus, it, "mean gradient")
             assert np.array_equal(a[2], b[2]), (cus, it, "parameters after the update")
-    record(f"dp_fullsize_{name}", rec)
+    record(f"dp_fullsize_{name}_overlap{overlap}", rec)
     # the collective that respects the cap must not stall the step: the whole gradient at 150 GB/s is 0.33-0.37 ms, most of it
     # under the backward pass (host-timed steps of ~2-4 ms: generous bound)
     assert rec["ms_world8_cus16"] < rec["ms_single"] + 0.6, rec
