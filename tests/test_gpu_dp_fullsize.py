@@ -12,7 +12,7 @@ its all-reduce that footprint: n workgroups that each own a whole CU (160 KB of 
   step is late, never wrong, and no spin times out.
 
 Either way loss, mean gradient and updated parameters are BIT-IDENTICAL to a context without a communicator and no step
-reports a persistent-kernel timeout.  Step times go to gpurun_out/parity_r03.jsonl.
+reports a persistent-kernel timeout.  Step times go to gpurun_out/parity_r04.jsonl.
 Reference anchor: 002_train_baseline.lua:323-329 (sum over clones, then clamp)."""
 import os
 import time

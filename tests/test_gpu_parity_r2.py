@@ -11,7 +11,7 @@
 * arch2's reference quirks (nvqa_set_ref_quirks) over three RMSprop iterations;
 * (round 3) the persistent two-chain BPTT kernel as the DEFAULT path: against the oracle, bit-reproducible, against the
   per-level fallback (NVQA_PERSIST_BWD=0), and its bounded give-up path (a spin limit of a few polls).
-Measured errors are appended to gpurun_out/parity_r03.jsonl (committed as profiles/r03_parity_measured_errors.jsonl); the
+Measured errors are appended to gpurun_out/parity_r04.jsonl (committed as profiles/r0N_parity_measured_errors.jsonl per round); the
 tolerances below are ~10x those measurements."""
 import os
 
