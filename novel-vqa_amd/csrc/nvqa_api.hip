@@ -57,8 +57,8 @@ static void prof_collect(nvqa_ctx *c)
             (void)hipEventSynchronize(p.second);
             (void)hipEventElapsedTime(&ms, p.first, p.second);
             c->prof[i].ms += ms;
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
+            c->prof_pool.push_back(p.first);
+            c->prof_pool.push_back(p.second);
         }
         c->prof[i].pending.clear();
     }
@@ -380,6 +380,8 @@ extern "C" int nvqa_destroy(nvqa_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     prof_collect(c);
+    for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
+    c->prof_pool.clear();
     comm_destroy(c);
     if (c->hset[0].tok) { // two device sets + pinned staging of the host-batch entries
         for (int p = 0; p < 2; ++p) {

@@ -198,4 +198,5 @@ struct nvqa_ctx {
     // profiling
     bool prof_on = false;
     nvqa::ProfEntry prof[nvqa::PF_COUNT];
+    std::vector<hipEvent_t> prof_pool; // events waiting for reuse (prof.h)
 };

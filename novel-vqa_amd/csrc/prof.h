@@ -12,8 +12,11 @@ struct ProfScope {
         : c(c_), id(id_), st(st_ ? st_ : c_->s)
     {
         if (!c->prof_on) return;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
+        // events come from a pool (prof_collect returns them): creating two per scope made the host the bottleneck of a profiled
+        // step -- the queue ran empty between launches and the first profiled steps measured 5-10 % long
+        auto take = [&]() { hipEvent_t e = nullptr; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        e0 = take();
+        e1 = take();
         (void)hipEventRecord(e0, st);
         c->prof[id].flops += flops;
         c->prof[id].bytes += bytes;
