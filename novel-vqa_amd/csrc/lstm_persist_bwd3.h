@@ -422,8 +422,6 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
                 ((af[PC + Pp] = ldA(bnxt[Pp % MTA], std::integral_constant<int, Pp / MTA>{})), ...);
             }(std::make_integer_sequence<int, PC>{});
         }
-#pragma unroll
-        for (int e = 0; e < NE; ++e) fetch(0, kstep(k0), e); // the cell operands of chain-step k0 (every later one: requested at the end of the chain-step before)
     }
 
     // one half-step: H = its half (compile time), k its index.  On entry the fragments of its first PD pairs are in flight and
@@ -452,8 +450,13 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
         // memory operations that are YOUNGER than the previous chain-step's stores at the signal point -- all unconditional: the
         // 5 NE cell operands requested right behind that cell backward, the fragments requested by the pairs in front of it, and
         // whichever of the UP flag, the UP tile and the producers' counter are requested in front of it
+        // this chain-step's cell operands (5 NE loads) are requested 16 pairs before the end of its stream -- 1.7 us of MFMAs in f32 --
+        // not earlier: 40 registers that are free during the stream are 10 more fragments in flight (PD = 32 in f32: with 16, a
+        // ragged batch's stream -- MFMAs of inactive tiles skipped, their fragment slots still cycled -- was bound by 128 loads / 16 in
+        // flight x 1.5 us = 12 us per chain-step whatever the row count)
+        constexpr int PFETCH = P > 16 ? P - 16 : 0;
         constexpr int NFRAG = TAILPF ? PSIG : 0; // (bf16: the stream requests nothing; chain-step k + 1's fragments are older than the stores)
-        constexpr int NYOUNG = 5 * NE + NFRAG + (PUPQ < PSIG ? 1 : 0) + (PV2 < PSIG ? NE : 0) + (PREQ < PSIG ? 1 : 0);
+        constexpr int NYOUNG = (PFETCH < PSIG ? 5 * NE : 0) + NFRAG + (PUPQ < PSIG ? 1 : 0) + (PV2 < PSIG ? NE : 0) + (PREQ < PSIG ? 1 : 0);
         static_assert(NYOUNG <= 63, "vmcnt is a 6-bit field");
         static_assert(PSIG <= P && (!TAILPF || PSIG < P), "the signal point lies in this chain-step");
         static_assert(PUPQ < PV2 && PV2 < P && PREQ >= 0 && PREQ < P, "a counter is requested before it is looked at");
@@ -480,6 +483,10 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
             constexpr int p = decltype(p_tag)::value, g = p / MT, m = p % MT, slot = (RB0 + p) % PD;
             if constexpr (p == PSIG) {
                 if (pub >= 0) { pb_wait_vmcnt<NYOUNG>(); signal_wave(pub); pub = -1; }
+            }
+            if constexpr (p == PFETCH) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) fetch(H, s, e);
             }
             if constexpr (p == PUPQ) {
                 pend_up = __hip_atomic_load(has_up ? up_word(k) : cnt_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -524,9 +531,6 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
         spill_acc(HT, k & 1);
         __syncthreads();
         cell_all(HT, s, true, nr, k & 1, false);
-        // the NEXT half-step's cell operands (the registers are free again; younger than this half-step's stores)
-#pragma unroll
-        for (int e = 0; e < NE; ++e) fetch(HN, sn, e);
         pub = k; // drained and signalled PSIG pairs into the next half-step (its first MFMAs run under the stores' trip to memory)
 #pragma unroll
         for (int m = 0; m < MTA; ++m) bcur[m] = bnxt[m];

@@ -1482,6 +1482,12 @@ static int upload_batch(nvqa_ctx *c, int n, const int32_t *tokens, const int32_t
     }
     c->batch_uniform = true;
     for (size_t b = 1; b < B; ++b) c->batch_uniform = c->batch_uniform && ln[b] == ln[0];
+    {   // share of the B x T (row, step) slots this batch fills (arch2 runs every row to the longest question): the persistent BPTT
+        // launch of a ragged arch1 batch is that much shorter, and so is what may ride in it (persist_bwd.hip)
+        double sl = 0;
+        for (size_t b = 0; b < B; ++b) sl += ln[b];
+        c->batch_len_frac = d.arch == NVQA_ARCH1 ? (float)(sl / ((double)B * T)) : 1.f;
+    }
     // ---- pinned staging -> the device set the running step does not read, on the side stream --------------------------------
     if (!c->hset[0].tok) { // first host-batch call: the second device set, two pinned staging sets, the events
         c->bset[0] = {c->tok, c->len, c->lab, c->img};
@@ -1753,6 +1759,9 @@ extern "C" int nvqa_dataset_load(nvqa_ctx *c, int64_t n_q, const int32_t *questi
     ds.uniform_len = true; // all questions of one length: every batch drawn from the dataset is full-length
     if (lengths)
         for (int64_t q = 1; q < n_q; ++q) ds.uniform_len = ds.uniform_len && lengths[q] == lengths[0];
+        double sl = 0;
+        for (int64_t q = 0; q < n_q; ++q) sl += lengths[q];
+        ds.mean_len_frac = (float)(sl / ((double)n_q * d.T)); // what a drawn batch's rows are expected to fill of the T steps
     if (l2_normalize > 1 && (l2_normalize >= d.I || l2_normalize % 4)) { set_error("l2_normalize split %d must be a multiple of 4 below I=%d", l2_normalize, d.I); return -1; }
     if (l2_normalize > 1) {
         hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I, 0, l2_normalize);
@@ -1776,6 +1785,7 @@ extern "C" int nvqa_step_indices(nvqa_ctx *c, const int64_t *qinds, const nvqa_d
         if (qinds[b] < 0 || qinds[b] >= c->ds.n_q) { set_error("qinds[%d]=%lld outside 0..%lld", b, (long long)qinds[b], (long long)c->ds.n_q - 1); return -1; }
     NVQA_HIP(hipSetDevice(c->device));
     c->batch_uniform = c->ds.uniform_len;
+    c->batch_len_frac = d.arch == NVQA_ARCH1 ? c->ds.mean_len_frac : 1.f;
     {
         ProfScope ps(c, PF_GATHER, 0, 2.0 * d.B * d.I * 4);
         if (d.B <= NVQA_QARG_MAX && c->ds.n_q <= 0x7fffffffLL) { // the ids as kernel arguments (kernels.h: no H2D blit in front of the step)

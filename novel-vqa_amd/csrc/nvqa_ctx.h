@@ -78,6 +78,7 @@ struct Dataset {
     int32_t *Q = nullptr, *QL = nullptr, *IP = nullptr, *ANS = nullptr;
     float *F = nullptr;
     bool uniform_len = false; // every question has the same length (host check at load)
+    float mean_len_frac = 1.f; // mean question length / T (host, at load)
 };
 
 } // namespace nvqa
@@ -151,6 +152,7 @@ struct nvqa_ctx {
     bool bf16 = false;            // nvqa_set_precision: GEMM operands rounded to bf16, bf16 MFMA, f32 accumulate
     bool fold_i2h = true;         // layer-0 input projection as a first K segment of the level kernel; NVQA_FOLD_I2H=0: separate time-batched GEMM
     bool batch_uniform = false;   // current batch: all lengths equal (known on the host)
+    float batch_len_frac = 1.f;   // current batch: filled share of its B x T (row, step) slots (host batches: exact; dataset route: the dataset's mean)
     bool persist_on = false;      // forward LSTM as one persistent weight-stationary launch (lstm_persist.h)
     int num_cus = 0;
     unsigned *pf_cnt = nullptr;   // its arrival counters + err word (zeroed at creation and by the latch kernel behind every launch)

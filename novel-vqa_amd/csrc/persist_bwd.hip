@@ -109,18 +109,29 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
     const int n_idle = (8 * std::max(1, 32 / NU) - (2 * L - 1) * RB) * NU;
     const bool take_jobs = (c->tok_job_pending || c->ride_gemm_pending) && n_idle > 0 &&
                            (!c->tok_job_pending || tok_index_lds(c->ride.tok.VT, c->ride.tok.NP) <= 160 * 1024);
-    double ride_flops = 0;
-    if (take_jobs && c->ride_gemm_pending)
-        for (int i = 0; i < c->ride.ngemm; ++i) ride_flops += 2.0 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
     // (the calibration is for 7 row tiles per workgroup in f32 (B = 512: 0.9 ms then, 0.81 ms with the round-4 kernel)
-    // and 4 in bf16; a launch with fewer row tiles per workgroup is shorter in proportion, and so is what may ride in it)
+    // and 4 in bf16; a launch with fewer row tiles per workgroup is shorter in proportion, and so is what may ride in it.  Round 4: so is
+    // the launch of a RAGGED batch -- its roles are done after 0.62 ms at a mean length of 0.56 T (0.81 ms at full length) while 3.2
+    // GFLOP of riders kept the launch alive for 0.80 ms: measured, ragged step 2.39 -> 2.26 ms with the products behind the launch --
+    // roles(f) = roles(1) x (0.47 + 0.53 f) with f the filled share of the batch's (row, step) slots.)
     const int tiles_wg = ((B + 15) / 16 + RB - 1) / RB;
-    const double bptt_ms = 1e-3 * TS * (c->bf16 ? 16.0 : 31.0) * (L == 1 ? 0.62 : 1.0) * std::min(1.0, tiles_wg / (c->bf16 ? 4.0 : 7.0));
+    const double len_scale = d.arch == NVQA_ARCH1 && !c->batch_uniform ? 0.47 + 0.53 * std::min(1.f, std::max(0.f, c->batch_len_frac)) : 1.0;
+    const double bptt_ms = 1e-3 * TS * (c->bf16 ? 16.0 : 31.0) * (L == 1 ? 0.62 : 1.0) * std::min(1.0, tiles_wg / (c->bf16 ? 4.0 : 7.0)) * len_scale;
     static const double ride_cap = [] { const char *e = getenv("NVQA_RIDE_CAP"); return e ? atof(e) : 3.8; }(); // GFLOP per 0.90 ms and 16 riders
     // (round 4: 3.4 -> 3.8 with the direct-operand kernel: the 3.2 GFLOP of dW_o + dW_q still end before its roles do -- measured: step 2.926 ms with
-    // them riding, 2.969 with them behind the launch -- and the launch estimate below shrank with the kernel)
-    const bool keep_gemms = ride_flops * 1e-9 > ride_cap * (bptt_ms / 0.90) * (n_idle / 16.0);
-    if (keep_gemms) ride_flops = 0;
+    // them riding, 2.969 with them behind the launch -- and the launch estimate above shrank with the kernel)
+    const double cap_flops = 1e9 * ride_cap * (bptt_ms / 0.90) * (n_idle / 16.0);
+    // the products ride in list order as long as they fit; the rest is computed behind the launch (ride_flush)
+    int n_ride = 0;
+    double ride_flops = 0;
+    if (take_jobs && c->ride_gemm_pending)
+        for (int i = 0; i < c->ride.ngemm; ++i) {
+            const double fl = 2.0 * c->ride.gm[i].g.M * c->ride.gm[i].g.N * c->ride.gm[i].g.K;
+            if (ride_flops + fl > cap_flops) break;
+            ride_flops += fl;
+            n_ride = i + 1;
+        }
+    const bool keep_gemms = take_jobs && c->ride_gemm_pending && n_ride < c->ride.ngemm; // some (or all) stay behind
     // (the riding products are booked under an entry of their own -- they run on CUs the BPTT roles do not use,
     // and counting their FLOPs in the BPTT phase would flatter its fraction of the peak)
     if (c->prof_on && ride_flops > 0) { c->prof[PF_RIDE].flops += ride_flops; c->prof[PF_RIDE].launches += 1; }
@@ -152,7 +163,7 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
             c->ride.has_tok = c->tok_job_pending ? 1 : 0;
             if (!c->ride_gemm_pending) c->ride.ngemm = c->ride.has_colsum = 0;
             RideJobs kept = c->ride;
-            if (keep_gemms) c->ride.ngemm = 0;
+            if (keep_gemms) c->ride.ngemm = n_ride;
             if (!c->ride_dev) NVQA_HIP(hipMalloc((void **)&c->ride_dev, sizeof(RideJobs)));
             if (memcmp(&c->ride_dev_host, &c->ride, sizeof(RideJobs)) != 0) { // (the same list every step: uploaded once)
                 NVQA_HIP(hipMemcpyAsync(c->ride_dev, &c->ride, sizeof(RideJobs), hipMemcpyHostToDevice, c->s));
@@ -161,8 +172,10 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
             }
             a.jobs = c->ride_dev;
             c->tok_job_pending = c->ride_gemm_pending = false;
-            if (keep_gemms) { // ride_flush computes them behind the launch (the column sums went along)
+            if (keep_gemms) { // ride_flush computes what did not fit behind the launch (the column sums went along)
                 c->ride = kept;
+                for (int i = n_ride; i < kept.ngemm; ++i) c->ride.gm[i - n_ride] = kept.gm[i];
+                c->ride.ngemm = kept.ngemm - n_ride;
                 c->ride.has_colsum = 0;
                 c->ride_gemm_pending = true;
             }
@@ -172,9 +185,12 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         if (rag) NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, true>(c, a, grid)));                    \
         else NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, false>(c, a, grid)));                       \
     } while (0)
-#define NVQA_PB3_GO(GKT, TILES, NH, NTN, PD, BFv)                                                                   \
+    // PD / PDR: fragments in flight per lane in the equal-length / the ragged instance.  A ragged stream skips the MFMAs of row tiles
+    // without active rows but still cycles their ring slots, so it is bound by loads in flight x latency, not by MFMAs: as deep a ring
+    // as the registers allow (28 quads; 32 spills)
+#define NVQA_PB3_GO(GKT, TILES, NH, NTN, PD, PDR, BFv)                                                              \
     do {                                                                                                             \
-        if (rag) NVQA_TRY((launch_persist_bwd3<GKT, TILES, NH, NTN, PD, BFv, true>(c, a, grid)));                    \
+        if (rag) NVQA_TRY((launch_persist_bwd3<GKT, TILES, NH, NTN, PDR, BFv, true>(c, a, grid)));                   \
         else NVQA_TRY((launch_persist_bwd3<GKT, TILES, NH, NTN, PD, BFv, false>(c, a, grid)));                       \
     } while (0)
         // f32: the direct-operand kernel (0.89 -> 0.81 ms); bf16: round 3's ring kernel is still the faster one (0.46 against 0.54 ms:
@@ -189,9 +205,9 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
                 if (MT == 4) NVQA_PB2_GO(32, 2, 2, 2, 2, false); else NVQA_PB2_GO(32, 4, 3, 2, 2, false);
             }
         } else if (c->bf16) { // four chains of one row tile (a chain-step is ~2 us: two chains do not hide a 5 us hand-off)
-            if (L == 1) NVQA_PB3_GO(16, 4, 4, 2, 32, true); else NVQA_PB3_GO(16, 4, 4, 4, 32, true);
+            if (L == 1) NVQA_PB3_GO(16, 4, 4, 2, 32, 32, true); else NVQA_PB3_GO(16, 4, 4, 4, 32, 32, true);
         } else {              // two chains of 2 + 2 or 4 + 3 row tiles
-            if (MT == 4) NVQA_PB3_GO(32, 4, 2, 2, 16, false); else NVQA_PB3_GO(32, 7, 2, 2, 16, false);
+            if (MT == 4) NVQA_PB3_GO(32, 4, 2, 2, 16, 16, false); else NVQA_PB3_GO(32, 7, 2, 2, 16, 28, false);
         }
 #undef NVQA_PB3_GO
 #undef NVQA_PB2_GO
