@@ -461,10 +461,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
         static_assert(PSIG <= P && (!TAILPF || PSIG < P), "the signal point lies in this chain-step");
         static_assert(PUPQ < PV2 && PV2 < P && PREQ >= 0 && PREQ < P, "a counter is requested before it is looked at");
         const auto HT = std::integral_constant<int, H>{};
-        const auto HNT = std::integral_constant<int, HN>{};
         const int s = kstep(k);
-        const bool more = k + 1 < KN;
-        const int kn = more ? k + 1 : k, sn = kstep(kn), san = ksa(kn);
         // the chain-step whose fragments THIS one requests: the next (f32: in its tail) or the one after (bf16: behind its stream)
         constexpr int LOOK = TAILPF ? 1 : 2, HL = (H + LOOK) % NH, MTL = pb3_mt(TILES, NH, HL);
         const bool morel = k + LOOK < KN;

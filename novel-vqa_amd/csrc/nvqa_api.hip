@@ -1757,11 +1757,13 @@ extern "C" int nvqa_dataset_load(nvqa_ctx *c, int64_t n_q, const int32_t *questi
     ds.n_q = n_q;
     ds.n_img = n_img;
     ds.uniform_len = true; // all questions of one length: every batch drawn from the dataset is full-length
-    if (lengths)
+    ds.mean_len_frac = 1.f;
+    if (lengths) {
         for (int64_t q = 1; q < n_q; ++q) ds.uniform_len = ds.uniform_len && lengths[q] == lengths[0];
         double sl = 0;
         for (int64_t q = 0; q < n_q; ++q) sl += lengths[q];
         ds.mean_len_frac = (float)(sl / ((double)n_q * d.T)); // what a drawn batch's rows are expected to fill of the T steps
+    }
     if (l2_normalize > 1 && (l2_normalize >= d.I || l2_normalize % 4)) { set_error("l2_normalize split %d must be a multiple of 4 below I=%d", l2_normalize, d.I); return -1; }
     if (l2_normalize > 1) {
         hipLaunchKernelGGL(k_l2norm_rows, dim3((unsigned)((n_img + 3) / 4)), dim3(256), 0, c->s, ds.F, n_img, d.I, 0, l2_normalize);

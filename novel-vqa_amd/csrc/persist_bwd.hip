@@ -52,18 +52,6 @@ template <class K> static int check_resident(nvqa_ctx *c, K kernel, size_t lds, 
     return 0;
 }
 
-template <int GKT, int MTA, int MTB, int NTN, int GPC, bool BF, bool RAG>
-static int launch_persist_bwd2(nvqa_ctx *c, const PersistBwd2Args &a, int grid)
-{
-    size_t lds = PersistBwd2Geom<MTA, MTB, NTN, GPC>::LDS_BYTES;
-    if (a.jobs && c->ride.has_tok) lds = std::max(lds, tok_index_lds(c->ride.tok.VT, c->ride.tok.NP));
-    static int resident = -1;
-    NVQA_TRY(check_resident(c, k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>, lds, grid, &resident));
-    hipLaunchKernelGGL((k_lstm_bwd_persist2<GKT, MTA, MTB, NTN, GPC, BF, RAG>), dim3(grid), dim3(NVQA_PF_THREADS), lds, c->s, a);
-    NVQA_HIP(hipGetLastError());
-    return 0;
-}
-
 // round 4: the direct-operand form (lstm_persist_bwd3.h); NVQA_BWD_KERNEL=2 keeps round 3's LDS-ring form (A/B runs, fallback tests)
 template <int GKT, int TILES, int NH, int NTN, int PD, bool BF, bool RAG>
 static int launch_persist_bwd3(nvqa_ctx *c, PersistBwd2Args a, int grid)
@@ -180,11 +168,6 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
                 c->ride_gemm_pending = true;
             }
         }
-#define NVQA_PB2_GO(GKT, MTA, MTB, NTN, GPC, BFv)                                                                   \
-    do {                                                                                                             \
-        if (rag) NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, true>(c, a, grid)));                    \
-        else NVQA_TRY((launch_persist_bwd2<GKT, MTA, MTB, NTN, GPC, BFv, false>(c, a, grid)));                       \
-    } while (0)
     // PD / PDR: fragments in flight per lane in the equal-length / the ragged instance.  A ragged stream skips the MFMAs of row tiles
     // without active rows but still cycles their ring slots, so it is bound by loads in flight x latency, not by MFMAs: as deep a ring
     // as the registers allow (28 quads; 32 spills)
@@ -197,20 +180,14 @@ int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB)
         // DESIGN.md section 4.6 says where the direct form loses in that mode).  NVQA_BWD_KERNEL=2 / 3 forces one of them.
         static const int ver_env = [] { const char *e = getenv("NVQA_BWD_KERNEL"); return e ? atoi(e) : 0; }();
         const int ver = ver_env ? ver_env : (c->bf16 ? 2 : 3);
-        if (ver == 2) {
-            if (c->bf16) {
-                // (4 K groups per chunk -- half the barriers -- measured slower: 0.52 vs 0.45 ms; the step is a chain of latencies)
-                if (L == 1) NVQA_PB2_GO(16, 2, 2, 2, 2, true); else NVQA_PB2_GO(16, 2, 2, 4, 2, true);
-            } else {
-                if (MT == 4) NVQA_PB2_GO(32, 2, 2, 2, 2, false); else NVQA_PB2_GO(32, 4, 3, 2, 2, false);
-            }
+        if (ver == 2) { // (the ring kernel's instances live in a translation unit of their own: persist_bwd_ring.hip)
+            NVQA_TRY(launch_persist_bwd_ring(c, a, grid, MT, rag));
         } else if (c->bf16) { // four chains of one row tile (a chain-step is ~2 us: two chains do not hide a 5 us hand-off)
             if (L == 1) NVQA_PB3_GO(16, 4, 4, 2, 32, 32, true); else NVQA_PB3_GO(16, 4, 4, 4, 32, 32, true);
         } else {              // two chains of 2 + 2 or 4 + 3 row tiles
             if (MT == 4) NVQA_PB3_GO(32, 4, 2, 2, 16, 16, false); else NVQA_PB3_GO(32, 7, 2, 2, 16, 28, false);
         }
 #undef NVQA_PB3_GO
-#undef NVQA_PB2_GO
     }
     NVQA_TRY(persist_latch_err(c, c->pb_cnt, c->pb_cnt_words, 4));
     return 0;

@@ -22,6 +22,9 @@ int latch_flush(nvqa_ctx *c);                 // ... or, where none does, k_err_
 // BPTT as one launch: row tiles per workgroup (0: not eligible / switched off), row blocks in *RB
 int persist_bwd_rows(const nvqa_ctx *c, int *RB);
 int lstm_backward_persist(nvqa_ctx *c, const Drop &dr, int MT, int RB);
+// the LDS-ring kernel's instances (persist_bwd_ring.hip)
+struct PersistBwd2Args;
+int launch_persist_bwd_ring(nvqa_ctx *c, const PersistBwd2Args &a, int grid, int MT, bool rag);
 // words of the counter block c->pb_cnt must hold (both kernels), for nvqa_create
 size_t persist_bwd_counter_words(const nvqa_dims &d, int TS);
 
