@@ -164,7 +164,7 @@ int nvqa_set_precision(nvqa_ctx *ctx, int bf16);
 #define NVQA_QUIRK_H0 1
 #define NVQA_QUIRK_LOOKUP 2
 int nvqa_set_ref_quirks(nvqa_ctx *ctx, int flags);
-/* torch.norm(cnn_w), torch.norm(encoder_w_q), torch.norm(multimodal_w) of 003_train_vqa_arch2/002_train_baseline.lua:401-403
+/* torch.norm(cnn_w), torch.norm(encoder_w_q), torch.norm(multimodal_w) of 003_train_vqa_arch2/002_train_baseline.lua:402-404
  * (arch1: encoder_w_q, embedding_w_q, multimodal_w): the L2 norm of each of the three parameter segments in
  * nvqa_segments order, reduced on the device.  Synchronises the context's stream. */
 int nvqa_param_norms(nvqa_ctx *ctx, float out[3]);
