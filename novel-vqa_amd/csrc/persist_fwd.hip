@@ -151,6 +151,14 @@ int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT)
     // ragged arch1 batch (or lengths known only on the device: the dataset route of a ragged dataset): the instance that
     // skips the MFMAs of row tiles without active rows
     const bool rag = d.arch == NVQA_ARCH1 && !c->batch_uniform;
+    // NVQA_FWD_KERNEL: 1 = round 2's LDS-ring kernel (lstm_persist.h), 3 = round 4's direct-operand kernel (lstm_persist_fwd3.h;
+    // default where it has an instance: f32, row blocks of 8 row tiles, equal-length batches)
+    static const int fwd_kernel = [] { const char *e = getenv("NVQA_FWD_KERNEL"); return e ? atoi(e) : 0; }();
+    if (fwd_kernel != 1 && persist_fwd3_eligible(c, MT, rag)) {
+        NVQA_TRY(launch_persist_fwd3(c, a, grid, rag));
+        NVQA_TRY(persist_latch_err(c, c->pf_cnt, c->pf_cnt_words, 0));
+        return 0;
+    }
 #define NVQA_PF_GO(KA, MTv, BFv, RAGv) NVQA_TRY((launch_persist_fwd<KA, 512, MTv, BFv, RAGv>(c, a, grid)))
     if (d.E == 200) { // arch1
         if (c->bf16) {

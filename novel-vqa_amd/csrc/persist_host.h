@@ -12,6 +12,11 @@ int persist_rows(const nvqa_ctx *c);
 // the whole forward unroll as one launch (lstm_persist.h)
 int lstm_forward_persist(nvqa_ctx *c, const Drop &dr, int MT);
 
+// the direct-operand forward kernel's instances (persist_fwd3.hip; lstm_persist_fwd3.h)
+struct PersistFwdArgs;
+bool persist_fwd3_eligible(const nvqa_ctx *c, int MT, bool rag);
+int launch_persist_fwd3(nvqa_ctx *c, const PersistFwdArgs &a, int grid, bool rag);
+
 // bf16 + NVQA_QUIRK_H0: refresh the bf16 image of the top layer's step-0 hidden state after arch2_backward rewrote it
 int persist_reimage_h0_top(nvqa_ctx *c);
 // copies a launch's err record (device) into the sticky record at word `off` (0 forward, 4 BPTT) and that to the host
