@@ -153,16 +153,21 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
 
     pf_f32x4 acc[MTA][4];
     pf_u32x4 af[PD];
-    auto mfma_pair = [&](auto g_tag, auto m_tag, const pf_u32x4 &frag) __attribute__((always_inline)) {
+    // hook(i): called behind MFMA i = 4 w + gate of the pair: an LDS or vector-memory instruction to issue in the MFMA's shadow.
+    // (Vector ARITHMETIC does not hide there: the f32 MFMA runs at the vector f32 rate and the cell's instructions cost the same
+    // cycles between the MFMAs as behind them -- measured in round 4 with the cell cut into 33 and into 59 micro-steps behind the
+    // MFMAs of the next chain-step: 2 340 and 2 750 exposed cycles against 2 320 as one block; the LDS writes of the spill do hide.)
+    auto mfma_pair = [&](auto g_tag, auto m_tag, const pf_u32x4 &frag, auto &&hook) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value, m = decltype(m_tag)::value;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) { // (locals: operands named only inside an asm statement are not captured by the lambda)
+        [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+            ([&] __attribute__((always_inline)) { // (locals: operands named only inside an asm statement are not captured by the lambda)
+                constexpr int w = I / 4, gt = I % 4;
                 pf_f32x4 &c = acc[m][gt];
                 const float av = __builtin_bit_cast(pf_f32x4, frag)[w], bv = __builtin_bit_cast(pf_f32x4, bw[gt][g])[w];
                 asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(av), "a"(bv));
-            }
+                hook(std::integral_constant<int, I>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, 16>{});
     };
     auto touch_acc = [&] {
 #pragma unroll
@@ -174,7 +179,12 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
     auto nop_before_read = [&] { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); touch_acc(); };
 
     // epilogue ownership: thread -> (row rho = tid / 4 + 64 e of the chain, units u0 + 4 eq .. +3)
-    const int eq = tid & 3, erow = tid >> 2;
+    // The 16 quads of a wave are PERMUTED over its 16 rows: a ds_read_b128 is serviced in four fixed groups of 16 lanes (quads {0,3,5,6},
+    // {1,2,4,7}, {8,11,13,14}, {9,10,12,15}: MI355X_MICROARCH.md "LDS"), a row of the partial tile starts 4 banks after the row
+    // before it (SROW = 68), and a quad's four lanes read 16 consecutive banks -- so the quads of a group must sit on rows 4 apart
+    // ({a, a+4, a+8, a+12}: banks 0-15, 16-31, 32-47, 48-63) for the cell's 16 reads of partial tiles to be conflict-free (in lane
+    // order, rows 0, 3, 5, 6 of a group overlap 2- and 3-fold).  Which row a thread owns is free: stores stay 64 contiguous bytes per quad.
+    const int eq = tid & 3, erow = (tid >> 6) * 16 + (int)((0xFEAB6732DC894510ull >> (4 * ((tid >> 2) & 15))) & 15);
     auto eloc = [&](int h, int e) __attribute__((always_inline)) { const int rho = erow + 64 * e; return (rho & 15) + 16 * (NH * (rho >> 4) + h); };
     int esi[NH][NE]; // original batch row of the owned rows (the dropout stream is indexed by it)
 #pragma unroll
@@ -186,23 +196,12 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             *reinterpret_cast<pf_f32x4 *>(cs + ((h * NE + e) * NVQA_PF_THREADS + tid) * 4) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    auto spill_acc = [&](int buf) __attribute__((always_inline)) {
-        // ONE lane base + compile-time offsets (they fit the ds_write offset field): written as S[(... + 16 m + r) * SROW + ...] hipcc
-        // keeps all 64 addresses in registers across the stream -- and spills them in the layer >= 1 instances, which have no spare AGPR
-        float *const Sw = Sred + buf * SRED + (wave * ROWSH + 4 * lh) * SROW + li;
-        nop_before_read();
-#pragma unroll
-        for (int m = 0; m < MTA; ++m)
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Sw[(16 * m + r) * SROW + 16 * gt] = acc[m][gt][r];
-    };
+    const __amdgpu_buffer_rsrc_t r_gt = pf_rsrc(Gt_l, (size_t)TS * B * 4 * R * 4), r_cs = pf_rsrc(Cs_l, hs_bytes);
     // fused cell of chain h at step t (act = false: the row block has not started / has stopped: zeros), stores
     auto cell_item = [&](auto h_tag, auto e_tag, int t, bool act, int nr, int buf) __attribute__((always_inline)) {
         constexpr int h = decltype(h_tag)::value, e = decltype(e_tag)::value;
         const int rho = erow + 64 * e, iloc = eloc(h, e), grow = rb + RBn * iloc;
-        const float *const Sr = Sred + buf * SRED + rho * SROW + 4 * eq; // (one base + compile-time offsets, as in spill_acc)
+        const float *const Sr = Sred + buf * SRED + rho * SROW + 4 * eq; // (one base + compile-time offsets, as for the spill)
         if (rho >= ROWSH || grow >= B || (dbg & 2)) return;
         const bool on = act && grow < nr;
         pf_f32x4 gi = {0.f, 0.f, 0.f, 0.f}, gf = gi, go = gi, gg = gi, cn = gi, hn = gi, un = gi;
@@ -233,17 +232,16 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             }
         }
         *cst = cn;
-        const size_t srow_g = (size_t)t * B + grow;
-        float *gt = Gt_l + srow_g * 4 * R + u0 + 4 * eq;
-        *reinterpret_cast<pf_f32x4 *>(gt) = gi;
-        *reinterpret_cast<pf_f32x4 *>(gt + R) = gf;
-        *reinterpret_cast<pf_f32x4 *>(gt + 2 * R) = go;
-        *reinterpret_cast<pf_f32x4 *>(gt + 3 * R) = gg;
-        const size_t so = ((size_t)(t + 1) * B + grow) * R + u0 + 4 * eq;
-        *reinterpret_cast<pf_f32x4 *>(Cs_l + so) = cn;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, hn), r_h, (unsigned)(so * 4), 0, 16);
-        if (has_next)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, un), r_un, (unsigned)((srow_g * R + u0 + 4 * eq) * 4), 0, 16);
+        // 32-bit byte offsets (every buffer is < 4 GB): the 64-bit pointer arithmetic of plain stores was a fifth of the cell's instructions
+        const unsigned srow_g = (unsigned)t * B + grow, q4 = (unsigned)(u0 + 4 * eq);
+        const unsigned go_ = (srow_g * 4u * R + q4) * 4u, uo = (srow_g * R + q4) * 4u, so = uo + (unsigned)B * R * 4u; // so: slice t + 1 of Hs / Cs
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, gi), r_gt, go_, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, gf), r_gt, go_ + (unsigned)R * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, go), r_gt, go_ + 2u * R * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, gg), r_gt, go_ + 3u * R * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, cn), r_cs, so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, hn), r_h, so, 0, 16 /* sc1 */);
+        if (has_next) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, un), r_un, uo, 0, 16 /* sc1 */);
     };
     auto cell_all = [&](auto h_tag, int t, bool act, int nr, int buf) __attribute__((always_inline)) {
         [&]<int... E>(std::integer_sequence<int, E...>) __attribute__((always_inline)) { (cell_item(h_tag, std::integral_constant<int, E>{}, t, act, nr, buf), ...); }(std::make_integer_sequence<int, NE>{});
@@ -316,6 +314,8 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
         // (h_{-1} = 0; lstm_persist.h SKIP0: every layer above starts that much earlier)
         constexpr bool SKIP0 = G0Q != G1Q;
 
+        unsigned long long tm_st = 0, tm_sp = 0, tm_ba = 0, tm_ce = 0; // NVQA_PF_DBG & 128: shader cycles in the stream / last spill / barrier / cell
+        auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long { return (dbg & 128) ? __builtin_amdgcn_s_memtime() : 0ull; };
         auto chain_step = [&](auto h_tag, int k) __attribute__((always_inline)) {
             constexpr int H = decltype(h_tag)::value, HN = (H + 1) % NH;
             constexpr int MT = MTA, P = GQ * MT, PR = G0Q * MT; // pairs of the chain-step; first recurrent pair
@@ -341,6 +341,11 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt) acc[m][gt] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             nop_after_clear();
+            // this lane's corner of the partial tile of chain-step k.  ONE lane base + compile-time offsets (they fit the ds_write offset
+            // field): written as Sred[(... + 16 m + r) * SROW + ...] hipcc keeps all 64 addresses in registers across the stream -- and
+            // spills them in the layer >= 1 instances, which have no spare AGPR
+            float *const Sw = Sred + (k & 1) * SRED + (wave * ROWSH + 4 * lh) * SROW + li;
+            const unsigned long long tm0 = stamp();
             __builtin_amdgcn_sched_barrier(0);
 
             auto pair = [&](auto p_tag) __attribute__((always_inline)) {
@@ -368,7 +373,19 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
                     pend_rec = __hip_atomic_load(morel && tl > t_lo ? rec_word(kl) : cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("" ::: "memory");
                 }
-                if ((!RAG || m < act) && !(SKIP0 && g >= G0Q && skip_rec)) mfma_pair(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot]);
+                auto hook = [&](auto i_tag) __attribute__((always_inline)) {
+                    if constexpr (p >= P - (MT - 1)) {
+                        // the accumulators of row tile mq = p - (P - MT) - 1 took their last MFMA a pair ago: their 16 registers go to the
+                        // partial-tile buffer now, one ds_write behind each MFMA (as one block of 64 behind the stream: 850 cycles, now 290)
+                        constexpr int i = decltype(i_tag)::value, mq = p - (P - MT) - 1, gt = i / 4, r = i % 4;
+                        Sw[(16 * mq + r) * SROW + 16 * gt] = acc[mq][gt][r];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if ((!RAG || m < act) && !(SKIP0 && g >= G0Q && skip_rec)) mfma_pair(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot], hook);
+                else { // (no MFMAs at this pair: the hooks alone)
+                    [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (hook(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 16>{});
+                }
                 // the fragment PD pairs ahead takes the slot just consumed
                 if constexpr (p + PD < P) {
                     constexpr int gq = (p + PD) / MT, mq = (p + PD) % MT;
@@ -382,9 +399,18 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             };
             [&]<int... Pp>(std::integer_sequence<int, Pp...>) __attribute__((always_inline)) { (pair(std::integral_constant<int, Pp>{}), ...); }(std::make_integer_sequence<int, P>{});
 
-            spill_acc(k & 1);
+            const unsigned long long tm1 = stamp();
+            nop_before_read();
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) // the last row tile's accumulators (the others went out under the last pairs' MFMAs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Sw[(16 * (MT - 1) + r) * SROW + 16 * gt] = acc[MT - 1][gt][r];
+            const unsigned long long tm2 = stamp();
             __syncthreads();
+            const unsigned long long tm3 = stamp();
             cell_all(h_tag, t, true, nr, k & 1);
+            const unsigned long long tm4 = stamp();
+            tm_st += tm1 - tm0; tm_sp += tm2 - tm1; tm_ba += tm3 - tm2; tm_ce += tm4 - tm3;
             pub = k; // drained and signalled PSIG pairs into the next chain-step
         };
 
@@ -394,6 +420,7 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             }(std::make_integer_sequence<int, NH>{});
         }
         if (pub >= 0) signal_now(pub);
+        if ((dbg & 128) && tid == 0) { a.ts[blockIdx.x * 4] = tm_st; a.ts[blockIdx.x * 4 + 1] = tm_sp; a.ts[blockIdx.x * 4 + 2] = tm_ba; a.ts[blockIdx.x * 4 + 3] = tm_ce; }
     }
     // ---- steps after the row block has stopped (arch2: t >= tmax) -----------------------------------------------------------------
     for (int t = t_hi; t < TS; ++t) idle_step(t);
@@ -411,6 +438,7 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_fwd_persist3(Persis
     if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4] = wall_clock64();
     if (l == 0) persist_fwd3_layer<G0A, GR, TILES, 2, PD, RAG>(a, l, rb, ut, pf_smem);
     else persist_fwd3_layer<GR, GR, TILES, 2, PD, RAG>(a, l, rb, ut, pf_smem);
+    if ((a.dbg & 32) && threadIdx.x == 0) a.ts[blockIdx.x * 4 + 3] = (wall_clock64() << 4) | (unsigned long long)(l + 1); // step loop done; layer
     if (l == 0 && a.fr_on) { // the riding product (PersistFwdArgs::fr): tiles dealt round-robin to the layer-0 workgroups
         __syncthreads();
         const int me = ut * a.RB + rb, n = a.RB * a.NU, tx = a.fr.tx, total = tx * a.fr.ty;

@@ -461,6 +461,21 @@ static float loss_mean_host(const nvqa_ctx *c)
 static int check_persist(nvqa_ctx *c)
 {
     static const int ts_dbg = [] { const char *a = getenv("NVQA_PF_DBG"), *b = getenv("NVQA_PB_DBG"); return ((a ? atoi(a) : 0) | (b ? atoi(b) : 0)) & 32; }();
+    static const int seg_dbg = [] { const char *a = getenv("NVQA_PF_DBG"); return (a ? atoi(a) : 0) & 128; }();
+    if (seg_dbg && c->pf_ts) { // measurement only (lstm_persist_fwd3.h): shader cycles per chain-step in four segments, per layer, once
+        static int left = 3;
+        if (left > 0 && --left == 0) {
+            std::vector<unsigned long long> h(1024);
+            const int RB = (c->d.B + 127) / 128, groups = c->d.L * RB, n = groups * (c->d.R / 16);
+            if (n <= 256 && hipMemcpy(h.data(), c->pf_ts, 1024 * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                for (int l = 0; l < c->d.L; ++l) {
+                    double s4[4] = {0, 0, 0, 0}; int m = 0;
+                    for (int b = 0; b < n; ++b) if ((b % groups) / RB == l) { ++m; for (int i = 0; i < 4; ++i) s4[i] += (double)h[b * 4 + i]; }
+                    const double den = (double)m * 2 * c->TS;
+                    fprintf(stderr, "[nvqa] forward layer %d, cycles per chain-step (wave 0): stream %.0f, last spill %.0f, barrier %.0f, cell %.0f\n", l, s4[0] / den, s4[1] / den, s4[2] / den, s4[3] / den);
+                }
+        }
+    }
     if (ts_dbg && c->pf_ts) { // measurement only: phase times of the persistent kernels' workgroups (min / max over workgroups), once
         static int left = 3;
         if (left > 0 && --left == 0) {
@@ -476,6 +491,15 @@ static int check_persist(nvqa_ctx *c)
                     }
                     if (n) fprintf(stderr, "[nvqa] persistent %s: %d workgroups; weights resident after %.1f .. %.1f us, done after %.1f .. %.1f us\n",
                                    k ? "BPTT" : "forward", n, w_lo * 0.01, w_hi * 0.01, e_lo * 0.01, e_hi * 0.01);
+                    for (int l = 1; l <= 4 && !k; ++l) { // (lstm_persist_fwd3.h tags its workgroups: slot 3 = step loop done << 4 | layer + 1)
+                        unsigned long long lo = ~0ull, hi = 0, dlo = ~0ull, dhi = 0; int m = 0;
+                        for (int b = 0; b < 256; ++b) {
+                            const unsigned long long *t = &h[b * 4];
+                            if (!t[2] || (int)(t[3] & 15) != l) continue;
+                            ++m; lo = std::min(lo, (t[3] >> 4) - t0); hi = std::max(hi, (t[3] >> 4) - t0); dlo = std::min(dlo, t[2] - t0); dhi = std::max(dhi, t[2] - t0);
+                        }
+                        if (m) fprintf(stderr, "[nvqa]   layer %d: %d workgroups; step loop done after %.1f .. %.1f us, workgroup done after %.1f .. %.1f us\n", l - 1, m, lo * 0.01, hi * 0.01, dlo * 0.01, dhi * 0.01);
+                    }
                 }
         }
     }
