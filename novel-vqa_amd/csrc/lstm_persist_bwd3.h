@@ -298,8 +298,16 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
         if (head_now && has_up && s == s_head) hx = *reinterpret_cast<const pf_f32x4 *>(a.dHT + ((size_t)l * B + min(grow, B - 1)) * R + u0 + 4 * eq);
         pf_f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (prod) {
+            // the four reads FIRST, then the sum in wave order: written as v += S[..] in a loop hipcc issues one ds_read at a time and
+            // waits lgkmcnt(0) before each add -- four exposed LDS round trips per item (lstm_persist_fwd3.h: the same pattern was
+            // 1 900 of the forward cell's 2 250 cycles)
+            const float *const Sr = S + rho * SROW + 4 * eq;
+            pf_f32x4 q[4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += *reinterpret_cast<const pf_f32x4 *>(&S[(w * ROWSH + rho) * SROW + 4 * eq]);
+            for (int w = 0; w < 4; ++w) q[w] = *reinterpret_cast<const pf_f32x4 *>(&Sr[w * ROWSH * SROW]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += q[w];
         }
         const size_t srow_g = (size_t)s * B + grow;
         const unsigned uo = (unsigned)((srow_g * R + u0 + 4 * eq) * 4);
@@ -337,7 +345,10 @@ __global__ __launch_bounds__(NVQA_PF_THREADS, 1) void k_lstm_bwd_persist3(Persis
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, dgg), r_g, go + 3u * R * 4, 0, 16);
         if (grow < nr) { // bias gradient: column sums of dG (own LDS slot: no other thread touches it)
             pf_f32x4 *bs = reinterpret_cast<pf_f32x4 *>(bsum + tid * 4); // gate g at bs[g * NVQA_PF_THREADS]
-            bs[0] += dgi; bs[NVQA_PF_THREADS] += dgf; bs[2 * NVQA_PF_THREADS] += dgo; bs[3 * NVQA_PF_THREADS] += dgg;
+            // (four reads, then four adds and writes: as bs[g] += ... each read-modify-write waited for its own LDS round trip)
+            const pf_f32x4 b0 = bs[0], b1 = bs[NVQA_PF_THREADS], b2 = bs[2 * NVQA_PF_THREADS], b3 = bs[3 * NVQA_PF_THREADS];
+            __builtin_amdgcn_sched_barrier(0);
+            bs[0] = b0 + dgi; bs[NVQA_PF_THREADS] = b1 + dgf; bs[2 * NVQA_PF_THREADS] = b2 + dgo; bs[3 * NVQA_PF_THREADS] = b3 + dgg;
         }
         if constexpr (BF) { // the image the REC / UP products read (the f32 one stays what the weight gradients read)
             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));

@@ -207,15 +207,19 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
         pf_f32x4 gi = {0.f, 0.f, 0.f, 0.f}, gf = gi, go = gi, gg = gi, cn = gi, hn = gi, un = gi;
         pf_f32x4 *cst = reinterpret_cast<pf_f32x4 *>(cs + ((h * NE + e) * NVQA_PF_THREADS + tid) * 4);
         if (on) {
-            pf_f32x4 p[4];
+            // ALL 21 LDS reads first, then the sums: written as p[g] = S[..]; p[g] += S[..]; ... hipcc issues one read at a time and
+            // waits for it (lgkmcnt(0)) before the add -- 16 exposed LDS round trips, 1 900 of the cell's 2 250 cycles (r4 stamps)
+            pf_f32x4 q[4][4], bq[4], p[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                p[g] = *reinterpret_cast<const pf_f32x4 *>(&Sr[16 * g]);
 #pragma unroll
-                for (int w = 1; w < 4; ++w) p[g] += *reinterpret_cast<const pf_f32x4 *>(&Sr[w * ROWSH * SROW + 16 * g]);
-                p[g] += *reinterpret_cast<const pf_f32x4 *>(&biasL[4 * eq + 16 * g]);
+                for (int w = 0; w < 4; ++w) q[g][w] = *reinterpret_cast<const pf_f32x4 *>(&Sr[w * ROWSH * SROW + 16 * g]);
+                bq[g] = *reinterpret_cast<const pf_f32x4 *>(&biasL[4 * eq + 16 * g]);
             }
             const pf_f32x4 cp = *cst;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p[g] = ((q[g][0] + q[g][1]) + q[g][2]) + q[g][3] + bq[g]; // K-quarters in wave order, then the bias
             const uint64_t didx = ((((uint64_t)l) * B + esi[h][e]) * TS + t) * R + u0 + 4 * eq;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
