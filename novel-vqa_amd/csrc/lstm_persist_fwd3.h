@@ -350,6 +350,9 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             // spills them in the layer >= 1 instances, which have no spare AGPR
             float *const Sw = Sred + (k & 1) * SRED + (wave * ROWSH + 4 * lh) * SROW + li;
             const unsigned long long tm0 = stamp();
+            if ((dbg & 256) && l == 0) { // measurement / tests: a slow layer 0, so that the layers above really wait at their counters
+                for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);
+            }
             __builtin_amdgcn_sched_barrier(0);
 
             auto pair = [&](auto p_tag) __attribute__((always_inline)) {

@@ -30,14 +30,23 @@ static int launch_persist_fwd3_t(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 // shapes the direct-operand kernel has instances for: f32, R = 512, E = 200 or 512, row blocks of 8 row tiles
 bool persist_fwd3_eligible(const nvqa_ctx *c, int MT, bool rag)
 {
-    return !c->bf16 && MT == 8 && !rag && c->d.R == 512 && (c->d.E == 200 || c->d.E == 512);
+    // Verified (parity suite): equal-length batches whose row blocks are full (B a multiple of 128).  Ragged batches and B = 500
+    // (a partly filled last row tile) give losses 5e-5 .. 1e-4 off with E = 200 -- not found yet; they keep lstm_persist.h's kernel
+    // unless NVQA_FWD3_ALL=1 asks for this one (debugging).
+    static const int all_on = [] { const char *e = getenv("NVQA_FWD3_ALL"); return e ? atoi(e) : 0; }();
+    const bool full_blocks = !rag && c->d.B % 128 == 0;
+    return !c->bf16 && MT == 8 && (full_blocks || all_on) && c->d.R == 512 && (c->d.E == 200 || c->d.E == 512);
 }
 
 int launch_persist_fwd3(nvqa_ctx *c, const PersistFwdArgs &a, int grid, bool rag)
 {
-    (void)rag;
-    if (c->d.E == 200) NVQA_TRY((launch_persist_fwd3_t<200, 512, 8, 16, false>(c, a, grid)));
-    else NVQA_TRY((launch_persist_fwd3_t<512, 512, 8, 16, false>(c, a, grid)));
+    if (c->d.E == 200) {
+        if (rag) NVQA_TRY((launch_persist_fwd3_t<200, 512, 8, 16, true>(c, a, grid)));
+        else NVQA_TRY((launch_persist_fwd3_t<200, 512, 8, 16, false>(c, a, grid)));
+    } else {
+        if (rag) NVQA_TRY((launch_persist_fwd3_t<512, 512, 8, 16, true>(c, a, grid)));
+        else NVQA_TRY((launch_persist_fwd3_t<512, 512, 8, 16, false>(c, a, grid)));
+    }
     return 0;
 }
 
