@@ -391,6 +391,9 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
                 };
                 if ((!RAG || m < act) && !(SKIP0 && g >= G0Q && skip_rec)) mfma_pair(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot], hook);
                 else { // (no MFMAs at this pair: the hooks alone)
+                    // ... and then nothing separates the spill of row tile mq from that tile's last MFMAs, one pair back (RAG: a chain with
+                    // fewer active tiles than row tiles): an MFMA result needs its wait states before a ds_write reads it as data
+                    if constexpr (p >= P - (MT - 1)) nop_before_read();
                     [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (hook(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 16>{});
                 }
                 // the fragment PD pairs ahead takes the slot just consumed

@@ -30,9 +30,10 @@ static int launch_persist_fwd3_t(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 // shapes the direct-operand kernel has instances for: f32, R = 512, E = 200 or 512, row blocks of 8 row tiles
 bool persist_fwd3_eligible(const nvqa_ctx *c, int MT, bool rag)
 {
-    // Verified (parity suite): equal-length batches whose row blocks are full (B a multiple of 128).  Ragged batches and B = 500
-    // (a partly filled last row tile) give losses 5e-5 .. 1e-4 off with E = 200 -- not found yet; they keep lstm_persist.h's kernel
-    // unless NVQA_FWD3_ALL=1 asks for this one (debugging).
+    // The verified set: equal-length batches whose row blocks are full (B a multiple of 128).  The ragged instances are built but
+    // NOT correct with E = 200 (losses 5e-5 .. 2e-4 off, different from run to run: DESIGN.md section 4.6), so ragged batches keep
+    // lstm_persist.h's kernel, and so do batches with a partly filled last row block (B = 500) until that case has been through the
+    // same checks.  NVQA_FWD3_ALL=1 asks for this kernel wherever it has an instance (debugging).
     static const int all_on = [] { const char *e = getenv("NVQA_FWD3_ALL"); return e ? atoi(e) : 0; }();
     const bool full_blocks = !rag && c->d.B % 128 == 0;
     return !c->bf16 && MT == 8 && (full_blocks || all_on) && c->d.R == 512 && (c->d.E == 200 || c->d.E == 512);

@@ -7,6 +7,7 @@ run() { # name, env...
   env "$@" timeout -k 10 600 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_bench_launch.py ${K:+-k "$K"} > gpurun_out/r4/fallback_$name.log 2>&1
   echo "$name: $(tail -1 gpurun_out/r4/fallback_$name.log)"
 }
+run fwd_ring NVQA_FWD_KERNEL=1 &&
 run bwd_ring NVQA_BWD_KERNEL=2 &&
 run bwd_direct_bf16 NVQA_BWD_KERNEL=3 &&
 K="not timeout and not ride and not rides and not dp" &&
