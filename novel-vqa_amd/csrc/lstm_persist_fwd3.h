@@ -338,7 +338,10 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             const int kl = morel ? k + 1 : k, tl = kl / NH;
             const int act = act_of(H, t), actn = act_of(HN, tl);
             const int nr = nrows_p[t];
-            const bool rec_dep = t > t_lo;                                       // h_{t-1} is another workgroup's bytes
+            // h_{t-1} is other workgroups' bytes at every step but 0 (slice 0 is the constant initial state): at the row block's FIRST
+            // active step t_lo > 0 the slice was written -- as zeros -- by the idle steps of all NU unit-tile workgroups, and the layers
+            // without SKIP0 multiply it: they must have seen those zeros, not the previous batch's h (lstm_persist.h waits there too)
+            const bool rec_dep = t > 0;
             const bool skip_rec = SKIP0 && __builtin_amdgcn_readfirstlane((t == t_lo && !top_h0) ? 1 : 0) != 0;
 #pragma unroll
             for (int m = 0; m < MTA; ++m)
@@ -377,7 +380,7 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
                     bases0(std::integral_constant<int, HN>{}, tl, actn, morel, bb);
                 }
                 if constexpr (PRQ < 0 && p == PNRQ) { // the next chain-step looks at it before its first pair
-                    pend_rec = __hip_atomic_load(morel && tl > t_lo ? rec_word(kl) : cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend_rec = __hip_atomic_load(morel && tl > 0 ? rec_word(kl) : cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("" ::: "memory");
                 }
                 auto hook = [&](auto i_tag) __attribute__((always_inline)) {

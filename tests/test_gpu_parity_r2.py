@@ -232,6 +232,7 @@ def test_arch2_reference_quirks_over_three_iterations(pkg, orc, flags, L):
 PERSIST_CASES = {   # (dims, batch A full-length?, batch B: uniform length or None = ragged [arch1: falls back to the level path])
     "arch1_all26": (FULL1, True, 9),
     "arch1_ragged_then_back": (FULL1, True, None),
+    "arch1_ragged_first": (FULL1, False, None),     # a ragged batch on a fresh context (no rows left over from a full one), then another
     "arch2_L2": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=2, I=2048, C=4, A=1000), False, None),
     "arch2_L1": (dict(arch=2, B=512, T=26, V=14773, E=512, R=512, L=1, I=4096, C=4, A=1000), False, None),
     "arch1_B200": (dict(FULL1, B=200), True, 5),    # 13 row tiles: partial row block, fewer workgroups than CUs
