@@ -146,6 +146,7 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
     // RAG: active tiles of chain h at step t (rows dealt round-robin: the active local rows are a prefix)
     auto act_of = [&](int h, int t) __attribute__((always_inline)) -> int {
         if constexpr (!RAG) return MTA;
+        if (dbg & 1024) return MTA; // debugging: nothing skipped, nothing out of range
         const int nr = nrows_p[t < 0 ? 0 : (t >= TS ? TS - 1 : t)];
         const int tiles = ((nr > rb ? (nr - rb + RBn - 1) / RBn : 0) + 15) >> 4;
         return __builtin_amdgcn_readfirstlane(min(MTA, max((tiles - h + NH - 1) / NH, 0)));
@@ -168,6 +169,34 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
                 hook(std::integral_constant<int, I>{});
             }(), ...);
         }(std::make_integer_sequence<int, 16>{});
+    };
+    // RAG: the same 16 MFMAs, skipped when row tile m of the chain has no active row (m >= act) -- with the branch INSIDE the asm
+    // statement (one per K step w: 4 MFMAs).  A C++ `if (m < act)` around mfma_pair puts a control-flow join behind every pair, and at
+    // those joins hipcc moves the 64 accumulator registers between two homes with v_mov_b64 copies it schedules without knowing that
+    // the asm statements are MFMAs: the instance came out wrong in the lower register pair of every accumulator of the row tiles m >= 1
+    // (rows = 0, 1 mod 4 of their tile) even when nothing was skipped at run time (tests/dbg_rag_rows.py, NVQA_PF_DBG=1024).  Hidden
+    // from the compiler the stream stays the straight-line code of the instance without skips.  Same order of the sums: bit-identical.
+    auto mfma_pair_rag = [&](auto g_tag, auto m_tag, const pf_u32x4 &frag, int act) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_tag)::value, m = decltype(m_tag)::value;
+        [&]<int... W>(std::integer_sequence<int, W...>) __attribute__((always_inline)) {
+            ([&] __attribute__((always_inline)) {
+                pf_f32x4 &c0 = acc[m][0], &c1 = acc[m][1], &c2 = acc[m][2], &c3 = acc[m][3]; // (locals: see mfma_pair)
+                const int act_ = act;
+                const float av = __builtin_bit_cast(pf_f32x4, frag)[W];
+                const float b0 = __builtin_bit_cast(pf_f32x4, bw[0][g])[W], b1 = __builtin_bit_cast(pf_f32x4, bw[1][g])[W];
+                const float b2 = __builtin_bit_cast(pf_f32x4, bw[2][g])[W], b3 = __builtin_bit_cast(pf_f32x4, bw[3][g])[W];
+                asm volatile("s_cmp_gt_i32 %9, %10\n\t"
+                             "s_cbranch_scc0 1f\n\t"
+                             "v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n\t"
+                             "v_mfma_f32_16x16x4_f32 %1, %4, %6, %1\n\t"
+                             "v_mfma_f32_16x16x4_f32 %2, %4, %7, %2\n\t"
+                             "v_mfma_f32_16x16x4_f32 %3, %4, %8, %3\n"
+                             "1:"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                             : "v"(av), "a"(b0), "a"(b1), "a"(b2), "a"(b3), "s"(act_), "n"(m)
+                             : "scc");
+            }(), ...);
+        }(std::make_integer_sequence<int, 4>{});
     };
     auto touch_acc = [&] {
 #pragma unroll
@@ -361,7 +390,12 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             auto pair = [&](auto p_tag) __attribute__((always_inline)) {
                 constexpr int p = decltype(p_tag)::value, g = p / MT, m = p % MT, slot = p % PD;
                 if constexpr (p == PSIG) {
-                    if (pub >= 0) { pb_wait_vmcnt<NYOUNG>(); signal_wave(pub); pub = -1; }
+                    if (pub >= 0) {
+                        if (dbg & 2048) pb_wait_vmcnt<0>(); // debugging: full drain instead of the counted one
+                        else pb_wait_vmcnt<NYOUNG>();
+                        signal_wave(pub);
+                        pub = -1;
+                    }
                 }
                 if constexpr (p == PRQ) {
                     pend_rec = __hip_atomic_load(rec_dep ? rec_word(k) : cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -392,10 +426,18 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
-                if ((!RAG || m < act) && !(SKIP0 && g >= G0Q && skip_rec)) mfma_pair(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot], hook);
-                else { // (no MFMAs at this pair: the hooks alone)
-                    // ... and then nothing separates the spill of row tile mq from that tile's last MFMAs, one pair back (RAG: a chain with
-                    // fewer active tiles than row tiles): an MFMA result needs its wait states before a ds_write reads it as data
+                if (!(SKIP0 && g >= G0Q && skip_rec)) {
+                    // RAG: a pair of a row tile without active rows is skipped inside mfma_pair_rag; the last MT - 1 pairs, whose MFMAs
+                    // carry the spill of the tile before them, always multiply (an inactive tile's fragments are zeros: out-of-range loads)
+                    if constexpr (RAG && p < P - (MT - 1)) mfma_pair_rag(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot], act);
+                    else mfma_pair(std::integral_constant<int, g>{}, std::integral_constant<int, m>{}, af[slot], hook);
+                    // SKIP0: this `if` is a control-flow join, and behind the pairs that carry a spill hipcc parks the accumulators in a
+                    // second register set there -- v_mov_b64 copies that start 8 wait states behind the pair's last MFMA and read its
+                    // destination (tools/mfma_hazard_scan.py; an 8-pass MFMA needs 11): wait the difference out
+                    if constexpr (SKIP0 && p >= P - (MT - 1)) { asm volatile("s_nop 4" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                } else { // (no MFMAs at this pair: the hooks alone)
+                    // ... and then nothing separates the spill of row tile mq from that tile's last MFMAs, one pair back: an MFMA result
+                    // needs its wait states before a ds_write reads it as data
                     if constexpr (p >= P - (MT - 1)) nop_before_read();
                     [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (hook(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 16>{});
                 }
@@ -425,6 +467,7 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
             const unsigned long long tm4 = stamp();
             tm_st += tm1 - tm0; tm_sp += tm2 - tm1; tm_ba += tm3 - tm2; tm_ce += tm4 - tm3;
             pub = k; // drained and signalled PSIG pairs into the next chain-step
+            if (dbg & 512) { signal_now(k); pub = -1; } // debugging: no deferred signal
         };
 
         for (int k = K0; k < KN; k += NH) {

@@ -5,6 +5,10 @@
 #include "lstm_persist_fwd3.h"
 #include "persist_host.h"
 
+#ifndef NVQA_FWD3_RAGGED_DEFAULT
+#define NVQA_FWD3_RAGGED_DEFAULT 2
+#endif
+
 namespace nvqa {
 
 template <int KA, int KR, int TILES, int PD, bool RAG>
@@ -27,20 +31,33 @@ static int launch_persist_fwd3_t(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
     return 0;
 }
 
-// shapes the direct-operand kernel has instances for: f32, R = 512, E = 200 or 512, row blocks of 8 row tiles
+// How ragged batches (arch1, lengths not all equal) are run -- NVQA_FWD3_RAGGED:
+//   2  (default) this kernel's RAG instance: row tiles without active rows skip their loads and MFMAs.  Correct since the skip
+//      became a branch INSIDE the asm statements (lstm_persist_fwd3.h, mfma_pair_rag; DESIGN.md section 4.6 has the story of the
+//      C++ `if` it replaces); tests/test_gpu_fwd3.py holds it against the ring kernel row by row, the parity suite against the oracle
+//   1  this kernel's instance without skips: the cell masks inactive (row, step) slots in every instance, so it is correct on a
+//      ragged batch too -- it multiplies all rows (ragged step 2.35 ms against 2.19 ms)
+//   0  lstm_persist.h's ring kernel, RAG instance (2.25 ms)
+static int ragged_mode()
+{
+    static const int m = [] {
+        const char *e = getenv("NVQA_FWD3_RAGGED");
+        return e ? atoi(e) : NVQA_FWD3_RAGGED_DEFAULT;
+    }();
+    return m;
+}
+
+// shapes the direct-operand kernel has instances for: f32, R = 512, E = 200 or 512, row blocks of 8 row tiles.  Any B: a partly
+// filled last row block (the reference's default batch of 500) goes through the `li < nloc` masks of the loads and the `grow < B`
+// test of the cell (tests/test_gpu_b500.py holds both against the f64 oracle).
 bool persist_fwd3_eligible(const nvqa_ctx *c, int MT, bool rag)
 {
-    // The verified set: equal-length batches whose row blocks are full (B a multiple of 128).  The ragged instances are built but
-    // NOT correct with E = 200 (losses 5e-5 .. 2e-4 off, different from run to run: DESIGN.md section 4.6), so ragged batches keep
-    // lstm_persist.h's kernel, and so do batches with a partly filled last row block (B = 500) until that case has been through the
-    // same checks.  NVQA_FWD3_ALL=1 asks for this kernel wherever it has an instance (debugging).
-    static const int all_on = [] { const char *e = getenv("NVQA_FWD3_ALL"); return e ? atoi(e) : 0; }();
-    const bool full_blocks = !rag && c->d.B % 128 == 0;
-    return !c->bf16 && MT == 8 && (full_blocks || all_on) && c->d.R == 512 && (c->d.E == 200 || c->d.E == 512);
+    return !c->bf16 && MT == 8 && (!rag || ragged_mode() != 0) && c->d.R == 512 && (c->d.E == 200 || c->d.E == 512);
 }
 
 int launch_persist_fwd3(nvqa_ctx *c, const PersistFwdArgs &a, int grid, bool rag)
 {
+    if (rag && ragged_mode() != 2) rag = false;
     if (c->d.E == 200) {
         if (rag) NVQA_TRY((launch_persist_fwd3_t<200, 512, 8, 16, true>(c, a, grid)));
         else NVQA_TRY((launch_persist_fwd3_t<200, 512, 8, 16, false>(c, a, grid)));

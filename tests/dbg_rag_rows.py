@@ -1,4 +1,5 @@
-# debugging aid (not a test): which rows of a ragged E = 200 forward pass differ between the two persistent forward kernels
+# which rows of a ragged E = 200 forward pass differ between the two persistent forward kernels, under each debugging switch of the
+# direct-operand kernel (run by tests/test_gpu_fwd3.py; by hand: python tests/dbg_rag_rows.py)
 import os, sys, subprocess, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,19 +19,25 @@ if len(sys.argv) > 1:
     np.save(sys.argv[1], np.asarray(scores)); np.save(sys.argv[1] + ".lens.npy", np.asarray(lens))
     print(sys.argv[1], "repeat identical:", np.array_equal(scores, s2), "max repeat diff", float(np.abs(np.asarray(scores) - np.asarray(s2)).max()))
     sys.exit(0)
-out = {}
-for k in ("1", "3"):
-    f = f"/tmp/rag_{k}.npy"
-    subprocess.run([sys.executable, __file__, f], env=dict(os.environ, NVQA_FWD_KERNEL=k, NVQA_FWD3_ALL="1"), check=True)
-    out[k] = np.load(f)
-lens = np.load("/tmp/rag_1.npy.lens.npy")
-diff = np.abs(out["1"] - out["3"]).max(axis=1)
-order = np.argsort(-lens, kind="stable")           # sorted position of each row (longest first)
-pos = np.empty_like(order); pos[order] = np.arange(len(order))
-bad = np.nonzero(diff > 1e-4)[0]
-print("rows differing > 1e-4:", len(bad), "of", len(diff), "max diff", float(diff.max()))
-for b in bad[:40]:
-    print("row", int(b), "len", int(lens[b]), "sorted pos", int(pos[b]), "block", int(pos[b]) % 4, "local", int(pos[b]) // 4, "tile", int(pos[b]) // 4 // 16, "diff %.3g" % diff[b])
+# reference: round 2's ring kernel; then the direct-operand kernel under each debugging switch (csrc/lstm_persist_fwd3.h)
+VARIANTS = [("ring", {"NVQA_FWD_KERNEL": "1"}),
+            ("fwd3_rag_instance", {"NVQA_FWD_KERNEL": "3", "NVQA_FWD3_RAGGED": "2"}),
+            ("fwd3_instance_without_skips", {"NVQA_FWD_KERNEL": "3", "NVQA_FWD3_RAGGED": "1"}),
+            ("fwd3_rag_no_skips_at_run_time", {"NVQA_FWD_KERNEL": "3", "NVQA_FWD3_RAGGED": "2", "NVQA_PF_DBG": "1024"}),
+            ("fwd3_rag_signal_now", {"NVQA_FWD_KERNEL": "3", "NVQA_FWD3_RAGGED": "2", "NVQA_PF_DBG": "512"}),
+            ("fwd3_rag_slow_layer0", {"NVQA_FWD_KERNEL": "3", "NVQA_FWD3_RAGGED": "2", "NVQA_PF_DBG": "256"})]
 import collections
-print("by length:", sorted(collections.Counter(int(lens[b]) for b in bad).items()))
-print("by tile:", sorted(collections.Counter(int(pos[b]) // 4 // 16 for b in bad).items()))
+out = {}
+for name, env in VARIANTS:
+    f = f"/tmp/rag_{name}.npy"
+    r = subprocess.run([sys.executable, __file__, f], env=dict(os.environ, **env), capture_output=True, text=True)
+    print("==", name, env, "rc", r.returncode, r.stdout.strip().splitlines()[-1:] , r.stderr.strip()[-300:] if r.returncode else "", flush=True)
+    if r.returncode: continue
+    out[name] = np.load(f)
+    if name == "ring": lens = np.load(f + ".lens.npy"); continue
+    diff = np.abs(out["ring"] - out[name]).max(axis=1)
+    order = np.argsort(-lens, kind="stable")           # sorted position of each row (longest first)
+    pos = np.empty_like(order); pos[order] = np.arange(len(order))
+    bad = np.nonzero(diff > 1e-4)[0]
+    print("   rows differing > 1e-4:", len(bad), "of", len(diff), "max diff %.3g" % float(diff.max()))
+    print("   by tile:", sorted(collections.Counter(int(pos[b]) // 4 // 16 for b in bad).items()), " by row mod 4:", sorted(collections.Counter((int(pos[b]) // 4) % 4 for b in bad).items()), flush=True)
