@@ -34,7 +34,7 @@ static int launch_persist_fwd3_t(nvqa_ctx *c, const PersistFwdArgs &a, int grid)
 // How ragged batches (arch1, lengths not all equal) are run -- NVQA_FWD3_RAGGED:
 //   2  (default) this kernel's RAG instance: row tiles without active rows skip their loads and MFMAs.  Correct since the skip
 //      became a branch INSIDE the asm statements (lstm_persist_fwd3.h, mfma_pair_rag; DESIGN.md section 4.6 has the story of the
-//      C++ `if` it replaces); tests/test_gpu_fwd3.py holds it against the ring kernel row by row, the parity suite against the oracle
+//      C++ `if` it replaces); tests/test_gpu_fwd3.py holds it against the ring kernel row by row, the parity suite against the CPU restatement
 //   1  this kernel's instance without skips: the cell masks inactive (row, step) slots in every instance, so it is correct on a
 //      ragged batch too -- it multiplies all rows (ragged step 2.35 ms against 2.19 ms)
 //   0  lstm_persist.h's ring kernel, RAG instance (2.25 ms)
@@ -49,7 +49,7 @@ static int ragged_mode()
 
 // shapes the direct-operand kernel has instances for: f32, R = 512, E = 200 or 512, row blocks of 8 row tiles.  Any B: a partly
 // filled last row block (the reference's default batch of 500) goes through the `li < nloc` masks of the loads and the `grow < B`
-// test of the cell (tests/test_gpu_b500.py holds both against the f64 oracle).
+// test of the cell (tests/test_gpu_b500.py holds both against the CPU restatement).
 bool persist_fwd3_eligible(const nvqa_ctx *c, int MT, bool rag)
 {
     return !c->bf16 && MT == 8 && (!rag || ragged_mode() != 0) && c->d.R == 512 && (c->d.E == 200 || c->d.E == 512);
