@@ -1,4 +1,4 @@
-"""Static check of the compiled persistent kernels whose MFMAs are inline asm (csrc/lstm_persist_fwd3.h, lstm_persist_bwd3.h).
+"""Static check of the compiled persistent kernels whose MFMAs are inline asm (csrc/lstm_persist_fwd3.h, lstm_persist_bwd3.h, lstm_persist_bwd2.h).
 
 hipcc does not know that those asm statements are matrix instructions, so whatever IT places behind them -- the register copies
 of a control-flow join, a spill -- gets no wait states.  Round 4 lost the ragged instances of the forward kernel to exactly that
@@ -15,15 +15,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.parametrize("tu", ["persist_fwd3", "persist_bwd"])
-def test_no_reader_inside_an_inline_mfma_latency(tu, tmp_path):
+TUS = ["persist_fwd3", "persist_bwd", "persist_bwd_ring"]
+
+
+@pytest.fixture(scope="module")
+def listings(tmp_path_factory):
+    """the three translation units compiled to assembly side by side (the longest takes about 1.5 min)"""
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    asm = tmp_path / (tu + ".s")
-    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-c++20-extensions", "-I" + os.path.join(ROOT, "include"),
-                    "--cuda-device-only", "-S", "-o", str(asm), os.path.join(ROOT, "novel-vqa_amd", "csrc", tu + ".hip")],
-                   check=True, capture_output=True, timeout=900)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "novel-vqa_amd", "tools", "mfma_hazard_scan.py"), str(asm)], capture_output=True, text=True)
+    d = tmp_path_factory.mktemp("asm")
+    procs = {tu: subprocess.Popen([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-c++20-extensions", "-I" + os.path.join(ROOT, "include"),
+                                   "--cuda-device-only", "-S", "-o", str(d / (tu + ".s")), os.path.join(ROOT, "novel-vqa_amd", "csrc", tu + ".hip")],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE) for tu in TUS}
+    for tu, pr in procs.items():
+        out, err = pr.communicate(timeout=1200)
+        assert pr.returncode == 0, err.decode()[-2000:]
+    return d
+
+
+@pytest.mark.parametrize("tu", TUS)
+def test_no_reader_inside_an_inline_mfma_latency(tu, listings):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "novel-vqa_amd", "tools", "mfma_hazard_scan.py"), str(listings / (tu + ".s"))], capture_output=True, text=True)
     assert "findings" in r.stdout, r.stdout[-500:] + r.stderr[-500:]   # (kernels were found and walked)
     assert r.returncode == 0, r.stdout[-3000:]
 
