@@ -8,6 +8,8 @@ run() { # name, env...
   echo "$name: $(tail -1 gpurun_out/r4/fallback_$name.log)"
 }
 run fwd_ring NVQA_FWD_KERNEL=1 &&
+run fwd3_ragged_by_ring NVQA_FWD3_RAGGED=0 &&
+run fwd3_ragged_without_skips NVQA_FWD3_RAGGED=1 &&
 run bwd_ring NVQA_BWD_KERNEL=2 &&
 run bwd_direct_bf16 NVQA_BWD_KERNEL=3 &&
 K="not timeout and not ride and not rides and not dp" &&
