@@ -173,7 +173,7 @@ __device__ __forceinline__ void persist_fwd3_layer(const PersistFwdArgs &a, cons
     // RAG: the same 16 MFMAs, skipped when row tile m of the chain has no active row (m >= act) -- with the branch INSIDE the asm
     // statement (one per K step w: 4 MFMAs).  A C++ `if (m < act)` around mfma_pair puts a control-flow join behind every pair, and at
     // those joins hipcc moves the 64 accumulator registers between two homes with v_mov_b64 copies it schedules without knowing that
-    // the asm statements are MFMAs: the instance came out wrong in the lower register pair of every accumulator of the row tiles m >= 1
+    // the asm statements are MFMAs (the one instruction at fault was not identified): the instance came out wrong in the lower register pair of every accumulator of the row tiles m >= 1
     // (rows = 0, 1 mod 4 of their tile) even when nothing was skipped at run time (tests/dbg_rag_rows.py, NVQA_PF_DBG=1024).  Hidden
     // from the compiler the stream stays the straight-line code of the instance without skips.  Same order of the sums: bit-identical.
     auto mfma_pair_rag = [&](auto g_tag, auto m_tag, const pf_u32x4 &frag, int act) __attribute__((always_inline)) {
