@@ -424,6 +424,8 @@ def main():
                     "persistent": r["persistent"], "step_mfma_frac": r["step_mfma_frac"],
                     "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms")}}
         sec["arch1_ragged_U3_26"] = brief(bench_one(pkg, WORKLOAD, args, 0, local_rank, 1, None, args.steps, args.warmup, ragged=True))
+        # the reference's own default batch (-batch_size 500, 002_train_baseline.lua:31): a partly filled last row block in both persistent kernels
+        sec["arch1_batch500_reference_default"] = brief(bench_one(pkg, dict(WORKLOAD, B=500), args, 0, local_rank, 1, None, args.steps, args.warmup))
         sec["arch2_f32"] = brief(bench_one(pkg, WORKLOAD_ARCH2, args, 0, local_rank, 1, None, args.steps, args.warmup))
         sec["arch2_bf16"] = brief(bench_one(pkg, WORKLOAD_ARCH2, args, 0, local_rank, 1, None, args.steps, args.warmup, bf16=True))
         hb = bench_one(pkg, WORKLOAD, args, 0, local_rank, 1, None, args.steps, args.warmup, roofline=False, host_batches=True)
